@@ -1,0 +1,101 @@
+"""ctypes binding of libcfgpp_hip.so (the C ABI declared in include/cfgpp.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a
+``CfgppError`` is raised.  The product path never routes through ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcfgpp_hip.so")
+
+
+class CfgppError(RuntimeError):
+    pass
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int),
+        ("num_levels", C.c_int),
+        ("block_out_channels", C.c_int * 4),
+        ("layers_per_block", C.c_int),
+        ("level_has_attn", C.c_int * 4),
+        ("transformer_depth", C.c_int * 4),
+        ("num_heads", C.c_int * 4),
+        ("cross_attention_dim", C.c_int),
+        ("addition_embed", C.c_int),
+        ("addition_time_embed_dim", C.c_int),
+        ("addition_pooled_dim", C.c_int),
+        ("norm_groups", C.c_int),
+        ("sample_h", C.c_int), ("sample_w", C.c_int),
+        ("max_rows", C.c_int),
+    ]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
+
+# name -> (restype, argtypes); every symbol include/cfgpp.h declares
+PROTOTYPES = {
+    "cfgpp_last_error": (C.c_char_p, []),
+    "cfgpp_step_ddim": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
+    "cfgpp_kdiff_input": (_I, [_P, _P, _F, _I, _L, _P]),
+    "cfgpp_step_kdiff": (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_float), _I, _I, _I, _I, _L, _P]),
+    "cfgpp_unet_create": (_P, [C.POINTER(UNetConfigC), _I]),
+    "cfgpp_unet_destroy": (None, [_P]),
+    "cfgpp_unet_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),
+    "cfgpp_unet_missing": (_I, [_P]),
+    "cfgpp_unet_finalize": (_I, [_P]),
+    "cfgpp_unet_set_context": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
+    "cfgpp_unet_forward": (_I, [_P, _P, _I, _I, _F, _P, _I, _P]),
+    "cfgpp_unet_flops": (C.c_double, [_P, _I]),
+    "cfgpp_unet_device_bytes": (C.c_double, [_P]),
+    "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_conv_out": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_sinusoid": (_I, [_P, _F, _P, _I, _I, _I, _I, _P]),
+    "cfgpp_op_skinny_gemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_f16_to_f32_rows": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "cfgpp_op_igemm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _I, _P]),
+    "cfgpp_op_igemm_heads": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_igemm_force_config": (None, [_I]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and attach prototypes.  Raises CfgppError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CfgppError(
+            f"{LIB_PATH} not found: build it with `python -m cfgpp_amd.build` "
+            "(__graft_entry__.build()).  The HIP path has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise CfgppError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CfgppError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().cfgpp_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise CfgppError(f"{what} failed (rc={rc}): {last_error()}")

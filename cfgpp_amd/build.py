@@ -1,0 +1,80 @@
+"""Build libcfgpp_hip.so (gfx950) in-tree with hipcc.  No JIT cache, no torch
+extension machinery: plain ``hipcc -c`` per source + one link, so the ``.so``
+travels with the repo snapshot to the GPU box."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libcfgpp_hip.so")
+OBJ = os.path.join(CSRC, "_obj")
+
+SOURCES = [
+    # (file, extra flags)
+    ("errors.cpp", []),
+    ("step_kernels.hip", ["-ffp-contract=off"]),     # bit-exact sampler arithmetic: no fma contraction
+    ("norm_kernels.hip", []),
+    ("small_kernels.hip", []),
+    ("igemm_kernel.hip", []),
+    ("attn_kernel.hip", []),
+    ("unet.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(src: str, dst: str) -> bool:
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "cfgpp.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for f, extra in SOURCES:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, os.path.splitext(f)[0] + ".o")
+        if force or _newer(src, obj):
+            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", src, "-o", obj]
+            jobs.append((f, cmd))
+
+    def run(job):
+        f, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return f, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for f, rc, log in ex.map(run, jobs):
+                if verbose:
+                    print(f"[cfgpp build] {f}: {'ok' if rc == 0 else 'FAILED'}", flush=True)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {f}:\n{log}")
+    objs = [os.path.join(OBJ, os.path.splitext(f)[0] + ".o") for f, _ in SOURCES]
+    if force or jobs or not os.path.exists(OUT):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[cfgpp build] linked {OUT}", flush=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,67 @@
+"""Host-side coefficient tables for the fused step kernels.
+
+The reference computes every per-step scalar as a 0-dim fp32 CPU tensor
+(``at = alphas_cumprod[t]``, ``(1-at).sqrt()``, ``torch.exp(-h)`` ...) and lets
+PyTorch type promotion combine it with fp16 eps / fp32 latents.  The HIP
+kernels take plain fp32 coefficients; this module evaluates them with the same
+torch scalar expressions (bit-identical fp32) and applies the one promotion
+rule that is not visible in the formulas:
+
+  a 0-dim fp32 *tensor* written FIRST in ``s * x`` with x fp16 is rounded to
+  fp16 before the multiply on the torch-CPU path the golden vectors were
+  recorded on (``scalar_semantics="cpu"``, default);  torch-CUDA keeps it in
+  fp32 (``scalar_semantics="cuda"``).
+
+Reference lines: latent_diffusion.py:655-666, 901-908, 849-866; latent_sdxl.py:732-744, 892-919.
+"""
+from __future__ import annotations
+
+import torch
+
+F32 = torch.float32
+
+
+def _s(v) -> torch.Tensor:
+    return torch.as_tensor(v, dtype=F32).reshape(())
+
+
+def _first(s: torch.Tensor, half_operand: bool, semantics: str) -> float:
+    """value of a scalar written first in ``s * fp16_tensor``."""
+    if half_operand and semantics == "cpu":
+        return float(s.to(torch.float16).to(F32))
+    return float(s)
+
+
+def ddim_coeffs(a_tweedie, a_renoise, eps_half: bool = True, semantics: str = "cpu"):
+    """(c1, c2, c3, c4) for cfgpp_step_ddim:
+    z0t = (z - c1*A)/c2 ; z' = c3*z0t + c4*B with c1 = sqrt(1-a_tw), c2 = sqrt(a_tw),
+    c3 = sqrt(a_rn), c4 = sqrt(1-a_rn)  (latent_diffusion.py:663,666)."""
+    a_tw, a_rn = _s(a_tweedie), _s(a_renoise)
+    c1, c2, c3, c4 = (1 - a_tw).sqrt(), a_tw.sqrt(), a_rn.sqrt(), (1 - a_rn).sqrt()
+    return (_first(c1, eps_half, semantics), float(c2), float(c3), _first(c4, eps_half, semantics))
+
+
+def kdiff_input_scale_sd(sigma) -> float:
+    """divisor of ``x / (sigma**2 + 1)**0.5`` (latent_diffusion.py:229-230)."""
+    return float((_s(sigma) ** 2 + 1) ** 0.5)
+
+
+def kdiff_coeffs(lam, sigmas, i, first: bool, xl_form: bool, semantics: str = "cpu"):
+    """coef[9] for cfgpp_step_kdiff at step i and whether the Euler branch is taken.
+
+    ``first`` = ``old_denoised is None``.  Mirrors latent_diffusion.py:856-865 /
+    latent_sdxl.py:909-918 scalar arithmetic (t_fn = -log sigma)."""
+    sig, sig_next = _s(sigmas[i]), _s(sigmas[i + 1])
+    euler = bool(first or float(sig_next) == 0.0)
+    t_fn = lambda s: s.log().neg()  # noqa: E731
+    coef = [float(lam), float(sig), _first(-sig, True, semantics), float(sig.item()), float(sig_next), 0.0, 0.0, 1.0, 0.0]
+    if not euler:
+        t, t_next = t_fn(sig), t_fn(sig_next)
+        h = t_next - t
+        h_last = t - t_fn(_s(sigmas[i - 1]))
+        r = h_last / h
+        coef[5] = _first(-torch.exp(-h), True, semantics)
+        coef[6] = _first((-h).expm1(), True, semantics)
+        coef[7] = float(2 * r)
+        coef[8] = _first(torch.exp(-h), True, semantics)
+    return coef, euler

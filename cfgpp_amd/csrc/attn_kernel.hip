@@ -1,0 +1,218 @@
+// K6/K7: fused (flash-style) attention for the SD / SDXL UNet on gfx950.
+//
+//   O[b, q, h*d + :] = softmax(Q K^T * scale) V      Q,K: [B*heads][tok_pad][dp]   V^T: [B*heads][dp][tok_pad]
+//
+// Layout contract (written by the QKV GEMM epilogue, EPI_HEADS): head-major, head
+// dim zero-padded to dp = round_up(d, 32), V stored TRANSPOSED so that every MFMA
+// operand is a contiguous 8/16-byte LDS read and no cross-lane shuffles are needed:
+//   * S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows = keys, B = Q^T cols =
+//     queries): each lane ends up holding 16 scores of ONE query per 32-key tile.
+//   * Online softmax entirely in registers (one __shfl_xor(…,32) for the row max).
+//   * O^T += V^T P^T: the B operand (P^T) is exactly the lane's own 8 consecutive
+//     accumulator registers converted to fp16 (the MFMA k-slot <-> key assignment is
+//     free as long as A and B agree), the A operand is 2 x ds_read_b64 from V^T.
+//   * 4 waves x 32 queries per workgroup, 64-key tiles, register-prefetched K/V
+//     tiles, padded LDS rows (conflict-free ds_read_b128).
+// Cross-attention (77 keys padded to 128) uses the same kernel with nk_valid = 77.
+// softmax statistics and accumulation are fp32; P is rounded to fp16 for the PV
+// product (same as the reference's SDPA flash path under fp16 autocast).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const half_t* q; const half_t* k; const half_t* vt;
+    half_t* o;
+    int heads, d;         // real head dim
+    int nq, nk_valid;     // real query / key counts
+    int q_tok_pad, k_tok_pad;
+    int o_ld;             // heads*d
+    float scale_log2e;    // d^-0.5 * log2(e)
+};
+
+template <int D16, int DT>
+__global__ void __launch_bounds__(256)
+attn_kernel(const AttnArgs a) {
+    constexpr int DP = DT * 32;                  // padded head dim (row pitch of Q/K, rows of V^T)
+    constexpr int KPITCH = DP * 2 + 16;          // bytes per K row in LDS
+    constexpr int VPITCH = 64 * 2 + 16;          // bytes per V^T row in LDS (64 keys)
+    constexpr int CH = (64 * DP / 8) / 256;      // 16-B chunks per thread per tile (K and V each)
+    static_assert((64 * DP / 8) % 256 == 0, "tile/loader mismatch");
+    __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + DP * VPITCH];
+    char* Ks = smem;
+    char* Vs = smem + 64 * KPITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
+    const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
+    const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
+
+    // Q^T fragments (B operand): lane = query q0+l31, 8 consecutive d at ks*16 + hi*8
+    half8_t qf[D16];
+#pragma unroll
+    for (int ks = 0; ks < D16; ++ks)
+        qf[ks] = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (a.nk_valid + 63) >> 6;
+
+    // cooperative tile loaders: K tile = 64 rows x DP halfs, chunk id c -> (row = c / (DP/8), col8 = c % (DP/8))
+    //                           V tile = DP rows x 64 keys, chunk id c -> (row = c / 8, col8 = c % 8)
+    half8_t rk[CH], rv[CH];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = tid + j * 256;
+            const int kr = c / (DP / 8), kc = c - kr * (DP / 8);
+            rk[j] = *reinterpret_cast<const half8_t*>(Kb + (long)(t * 64 + kr) * DP + kc * 8);
+            const int vr = c >> 3, vc = c & 7;
+            rv[j] = *reinterpret_cast<const half8_t*>(Vb + (long)vr * a.k_tok_pad + t * 64 + vc * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int c = tid + j * 256;
+            const int kr = c / (DP / 8), kc = c - kr * (DP / 8);
+            *reinterpret_cast<half8_t*>(Ks + kr * KPITCH + kc * 16) = rk[j];
+            const int vr = c >> 3, vc = c & 7;
+            *reinterpret_cast<half8_t*>(Vs + vr * VPITCH + vc * 16) = rv[j];
+        }
+    };
+
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();            // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
+
+        // ---- S^T = K Q^T for two 32-key sub-tiles ----
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < D16; ++ks) {
+                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 32 + l31) * KPITCH + (ks * 16 + hi * 8) * 2);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (per query = per lane column; keys across regs and the two half-waves) ----
+        const int kbase = t * 64 + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+                float v = s[kt][r] * a.scale_log2e;
+                v = key < a.nk_valid ? v : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[kt][r] - m_new);
+                s[kt][r] = pv;
+                psum += pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                half8_t pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kt][8 * tt + j];
+                // k-slot j = b*4 + r  <->  key = kt*32 + 8*(2*tt + b) + 4*hi + r
+                const int kcol0 = kt * 32 + 16 * tt + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    const char* vrow = Vs + (i * 32 + l31) * VPITCH;
+                    const half4_t v0 = *reinterpret_cast<const half4_t*>(vrow + (kcol0) * 2);
+                    const half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + (kcol0 + 8) * 2);
+                    half8_t vf;
+                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- finalize: O = O^T / l, store token-major ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < a.nq) {
+        const int b = bh / a.heads, head = bh - b * a.heads;
+        half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = i * 32 + 8 * g + 4 * hi;
+                if (dd < a.d) {
+                    half4_t o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[i][4 * g + k] * inv_l);
+                    *reinterpret_cast<half4_t*>(orow + dd) = o;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// q [B*heads][q_tok_pad][dp], k [B*heads][k_tok_pad][dp], vt [B*heads][dp][k_tok_pad], all fp16, dp = round_up(d,32),
+// pads zero.  o [B][nq][heads*d] fp16.  q_tok_pad % 128 == 0, k_tok_pad % 64 == 0.
+int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
+                       int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream) {
+    CFGPP_REQUIRE(q && k && vt && o, "attention: null pointer");
+    CFGPP_REQUIRE(d % 4 == 0 && d > 0 && d <= 160, "attention: head dim %d unsupported (multiple of 4, <= 160)", d);
+    CFGPP_REQUIRE(q_tok_pad % 128 == 0 && q_tok_pad >= nq, "attention: q_tok_pad=%d (nq=%d) must be a multiple of 128", q_tok_pad, nq);
+    CFGPP_REQUIRE(k_tok_pad % 64 == 0 && k_tok_pad >= nk, "attention: k_tok_pad=%d (nk=%d) must be a multiple of 64", k_tok_pad, nk);
+    AttnArgs a;
+    a.q = (const half_t*)q; a.k = (const half_t*)k; a.vt = (const half_t*)vt; a.o = (half_t*)o;
+    a.heads = heads; a.d = d; a.nq = nq; a.nk_valid = nk; a.q_tok_pad = q_tok_pad; a.k_tok_pad = k_tok_pad;
+    a.o_ld = heads * d;
+    a.scale_log2e = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
+    dim3 grid(cdiv(nq, 128), B * heads);
+    hipStream_t s = (hipStream_t)stream;
+    const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
+#define ATTN_CASE(D16_, DT_) \
+    if (d16 == D16_ && dt == DT_) { hipLaunchKernelGGL((attn_kernel<D16_, DT_>), grid, dim3(256), 0, s, a); } else
+    ATTN_CASE(1, 1) ATTN_CASE(2, 1) ATTN_CASE(3, 2) ATTN_CASE(4, 2) ATTN_CASE(5, 3) ATTN_CASE(6, 3)
+    ATTN_CASE(8, 4) ATTN_CASE(10, 5)
+    { cfgpp_set_error("attention: no kernel instance for head dim %d", d); return -2; }
+#undef ATTN_CASE
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

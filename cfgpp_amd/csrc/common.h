@@ -1,0 +1,54 @@
+// Common types and helpers for the gfx950 kernels of libcfgpp_hip.so.
+// CDNA4 only: wave64, MFMA f16 32x32x16, 160 KiB LDS.  No portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CFGPP_WAVE 64
+
+// ---- error plumbing (no exception crosses the C ABI) -----------------------
+void cfgpp_set_error(const char* fmt, ...);
+#define CFGPP_HIP_CHECK(expr)                                                         \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            cfgpp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,             \
+                            hipGetErrorString(_e));                                   \
+            return -1;                                                                \
+        }                                                                             \
+    } while (0)
+#define CFGPP_REQUIRE(cond, ...)                                                      \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            cfgpp_set_error(__VA_ARGS__);                                             \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- activation layouts -----------------------------------------------------
+// Spatial activations live in HBM as halo-padded NHWC fp16: [N][H+2][W+2][C],
+// halo == 0 for ever (buffers are keyed by shape and only interiors are
+// written), so a 3x3 tap gather never needs a bounds check.
+// Transformer activations are token-major [N*H*W][C].
+struct RowMap {
+    // row m of a GEMM operand -> element offset.
+    // mode 0: linear            off = m * ld
+    // mode 1: padded NHWC       m=(n,y,x) over (H,W): ((n*(H+2)+y+1)*(W+2)+x+1)*ld
+    // mode 2: padded, stride 2  source is (2H,2W):   ((n*(2H+2)+2y+1)*(2W+2)+2x+1)*ld
+    // mode 3: padded, nearest-2x upsample: source is (H/2,W/2), per-tap address
+    int mode;
+    int H, W;     // OUTPUT spatial size the rows enumerate (modes 1..3)
+    int ld;       // elements per row / pixel
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

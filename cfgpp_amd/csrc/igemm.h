@@ -1,0 +1,42 @@
+// Argument block of the implicit-GEMM kernel (K1/K2/K3/K4/K5 of SURVEY.md section 2.1).
+#pragma once
+#include "common.h"
+
+enum IGemmEpi : int {
+    EPI_STORE = 0,    // out = acc (+bias) (+temb[batch]) (+resid)          fp16, row-mapped
+    EPI_GEGLU = 1,    // packed (value|gate) column pairs -> out[M][N/2] = v * gelu_erf(g)
+    EPI_HEADS = 2,    // scatter into head-major Q / K / V^T buffers for attention
+};
+
+struct IGemmArgs {
+    // ---- A operand (activations), up to two channel-concatenated sources ----
+    const half_t* a0;
+    const half_t* a1;
+    int C0, C1;        // channels of each source, multiples of 64 (C1 may be 0)
+    int taps;          // 1 (linear / 1x1) or 9 (3x3, pad 1)
+    int amode;         // 0 linear rows, 1 padded NHWC, 2 padded stride-2, 3 padded nearest-2x upsample
+    int H, W;          // OUTPUT spatial size (amode >= 1): rows m enumerate (n, y, x)
+    // ---- B operand: weights [N][K] fp16, K = taps*(C0+C1), k = tap*Cin + c ----
+    const half_t* w;
+    int M, N, K;
+    // ---- epilogue ----
+    int epi;
+    const float* bias;        // [N] fp32 or null (packed order for GEGLU)
+    const float* temb;        // [batch][temb_ld] fp32 or null; batch = m / (H*W)
+    int temb_ld;
+    int rows_per_batch;       // H*W of the OUTPUT (for temb / padded maps / heads)
+    const half_t* resid;      // residual or null
+    int rmode, rld;           // residual row map: 0 linear, 1 padded (H, W as above)
+    half_t* out;
+    int omode, old;           // output row map: 0 linear, 1 padded
+    float out_scale;          // multiplies acc before bias (1.0 normally)
+    // EPI_HEADS
+    half_t* hq; half_t* hk; half_t* hvt;
+    int part0;                // which part column 0 belongs to: 0=Q, 1=K (K,V projection)
+    int part_width;           // C: columns per part
+    int head_dim, head_dim_pad, heads;
+    int tok_pad;              // padded token count of K rows / V^T columns (>= rows_per_batch)
+    int q_tok_pad;            // padded token count of Q rows
+};
+
+int igemm_launch(const IGemmArgs& a, hipStream_t stream);

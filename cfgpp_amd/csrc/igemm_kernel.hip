@@ -1,0 +1,331 @@
+// Implicit-GEMM MFMA kernel for gfx950: conv3x3 (stride 1 / stride 2 / fused
+// nearest-2x upsample), conv1x1 and linear layers of the SD / SDXL UNet, all as
+//      D[n][m] = sum_k W[n][k] * X[m][k]           (fp16 in, fp32 accumulate)
+// with the activation rows X gathered on the fly from halo-padded NHWC (3x3
+// taps are plain pointer deltas, no bounds checks) or token-major tensors, and
+// from up to two channel-concatenated sources (skip-connection concat is never
+// materialised).
+//
+// CDNA4 mapping
+//   * v_mfma_f32_32x32x16_f16, "swapped" operands: MFMA-A = weights (rows = output
+//     feature n), MFMA-B = activations (cols = pixel/token m).  The accumulator then
+//     holds, per lane, 4 CONSECUTIVE output features of ONE pixel -> 8-byte fp16
+//     stores into row-major [m][n] outputs and cheap per-feature bias loads.
+//   * 64x64 (or 32x32) tile per wave, WM x WN waves per workgroup, BK = 64.
+//   * LDS tiles [rows][64 halfs] (128-B rows) with a 16-B-chunk XOR swizzle
+//     chunk ^= (row>>1)&7: ds_write_b128 (8-lane groups) and ds_read_b128 (16-lane
+//     groups of distinct rows) are both bank-conflict free.
+//   * register-staged double buffering: global loads of k-tile t+1 are issued before
+//     the MFMAs of tile t and written to the other LDS stage afterwards; one barrier
+//     per k-tile.
+//   * XCD-aware workgroup remap: consecutive tiles (sharing activation rows) stay on
+//     one XCD's L2.
+// Epilogues: bias, per-batch time-embedding add, residual add, GEGLU, and the
+// head-major Q / K / V^T scatter the attention kernel consumes.
+#include "igemm.h"
+
+namespace {
+
+__device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
+    const int b = m / HW, p = m - b * HW;
+    const int y = p / W, x = p - y * W;
+    return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
+}
+
+template <int WM, int WN, int WTM, int WTN>
+__global__ void __launch_bounds__(64 * WM * WN)
+igemm_kernel(const IGemmArgs p) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
+    constexpr int A_CH = BM / RSTEP, B_CH = BN / RSTEP;
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0, "tile/loader mismatch");
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- workgroup -> tile, XCD-aware (block b runs on XCD b % 8) ----
+    const int ntn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+
+    // ---- loader state ----
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int HW = p.rows_per_batch;
+    const int Cin = p.C0 + p.C1;
+    const int tiles_per_tap = Cin >> 6;
+    int a_pix[A_CH];
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+        int m = m0 + lrow + j * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        if (p.amode == 0) a_pix[j] = m;
+        else if (p.amode == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
+        else if (p.amode == 2) {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1) * (2 * p.W + 2) + 2 * x + 1;
+        } else {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap
+        }
+    }
+    const half_t* b_ptr[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        int n = n0 + lrow + j * RSTEP;
+        n = n < p.N ? n : p.N - 1;
+        b_ptr[j] = p.w + (long)n * p.K + lchunk * 8;
+    }
+    // LDS store offsets (swizzled), identical for both operands
+    int st_off[(A_CH > B_CH ? A_CH : B_CH)];
+#pragma unroll
+    for (int j = 0; j < (A_CH > B_CH ? A_CH : B_CH); ++j) {
+        const int r = lrow + j * RSTEP;
+        st_off[j] = r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4);
+    }
+
+    half8_t ra[A_CH], rb[B_CH];
+    const int KT = p.K >> 6;
+
+    auto load_tile = [&](int kt) {
+        const int tap = kt / tiles_per_tap;
+        const int cc = (kt - tap * tiles_per_tap) << 6;
+        const half_t* src; int cs, Cs;
+        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        int dpix = 0;
+        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
+        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int pix;
+            if (p.amode == 3) {
+                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
+            } else {
+                pix = a_pix[j] + dpix;
+            }
+            ra[j] = *reinterpret_cast<const half8_t*>(src + (long)pix * Cs + cs + lchunk * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const half8_t*>(b_ptr[j] + ((long)kt << 6));
+    };
+    auto store_tile = [&](int stage) {
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) *reinterpret_cast<half8_t*>(As + st_off[j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) *reinterpret_cast<half8_t*>(Bs + st_off[j]) = rb[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    // fragment read offsets: row = base + (lane&31), logical chunk = ks*2 + (lane>>5)
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    const int a_rd = (wm * WTM + frow) * 128;
+    const int b_rd = (wn * WTN + frow) * 128;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const char* As = smem + cur * STAGE_BYTES;
+        const char* Bs = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+            half8_t xa[MT], wb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
+    const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw0 + i * 32 + frow;
+        if (m >= p.M) continue;
+        const int b = (HW > 0) ? m / HW : 0;
+        const int tok = m - b * HW;
+        long orow = m, rrow = m;
+        if (p.omode == 1 || p.rmode == 1) {
+            const long pp = padded_pix(m, HW, p.W, p.H);
+            if (p.omode == 1) orow = pp;
+            if (p.rmode == 1) rrow = pp;
+        }
+        if (p.epi == EPI_STORE) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * p.out_scale;
+                    if (p.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    if (p.temb) {
+                        const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+                        v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+                    }
+                    if (p.resid) {
+                        const half4_t rr = *reinterpret_cast<const half4_t*>(p.resid + rrow * p.rld + n);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] += (float)rr[k];
+                    }
+                    half4_t o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                    *reinterpret_cast<half4_t*>(p.out + orow * p.old + n) = o;
+                }
+        } else if (p.epi == EPI_GEGLU) {
+            // packed columns: within every 64 packed columns, [0,32) = value, [32,64) = gate
+            if constexpr (NT >= 2) {
+#pragma unroll
+                for (int j = 0; j < NT; j += 2)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int pc = nw0 + j * 32 + 8 * g + 4 * fhi;   // packed value column
+                        if (pc >= p.N) continue;
+                        const int f = (pc >> 6) * 32 + (pc & 31);
+                        float v[4], gt[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
+                        if (p.bias) {
+                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
+                            const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
+                            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                            gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                        }
+                        half4_t o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (half_t)(v[k] * gelu_erf_f(gt[k]));
+                        *reinterpret_cast<half4_t*>(p.out + orow * p.old + f) = o;
+                    }
+            }
+        } else {  // EPI_HEADS
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    if (n >= p.N) continue;
+                    const int part = n / p.part_width + p.part0;
+                    const int cn = n % p.part_width;
+                    const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
+                    if (p.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                    }
+                    const long bh = (long)b * p.heads + head;
+                    if (part == 2) {
+                        half_t* dst = p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dst[(long)k * p.tok_pad] = (half_t)v[k];
+                    } else {
+                        half4_t o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                        half_t* base = part == 0 ? p.hq : p.hk;
+                        const int tp = part == 0 ? p.q_tok_pad : p.tok_pad;
+                        *reinterpret_cast<half4_t*>(base + (bh * tp + tok) * p.head_dim_pad + dd) = o;
+                    }
+                }
+        }
+    }
+}
+
+template <int WM, int WN, int WTM, int WTN>
+int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
+    constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN>;
+    if (!attr_set) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), smem, stream, a);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// forced tile config for tests / tuning: 0 = heuristic
+static int g_force_cfg = 0;
+extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
+
+int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
+    const int Cin = a.C0 + a.C1;
+    CFGPP_REQUIRE(a.C0 > 0 && a.C0 % 64 == 0 && a.C1 % 64 == 0, "igemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
+    CFGPP_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps=%d", a.taps);
+    CFGPP_REQUIRE(a.K == a.taps * Cin, "igemm: K=%d != taps*Cin=%d", a.K, a.taps * Cin);
+    CFGPP_REQUIRE(a.N % 4 == 0 && a.M > 0 && a.N > 0, "igemm: M=%d N=%d (N must be a multiple of 4)", a.M, a.N);
+    CFGPP_REQUIRE(a.amode == 0 || (a.H > 0 && a.W > 0 && a.rows_per_batch == a.H * a.W), "igemm: spatial args");
+    CFGPP_REQUIRE(a.amode != 3 || (a.H < 2048 && a.W < 2048 && (a.M / a.rows_per_batch) < 512), "igemm: upsample range");
+    CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
+    CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
+    // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for
+    // N = 64*odd (e.g. 320), 64x64 (4 waves of 32x32) for small problems.
+    int cfg = g_force_cfg;
+    if (cfg == 0) {
+        const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        const long t256x64 = (long)cdiv(a.M, 256) * cdiv(a.N, 64);
+        const bool n_odd64 = (a.N % 128) != 0;
+        if (t128 >= 256 && !n_odd64) cfg = 1;
+        else if (t256x64 >= 256 && (n_odd64 || a.N <= 64)) cfg = 2;
+        else if (t128 >= 200) cfg = 1;
+        else cfg = 3;
+        if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<2, 2, 64, 64>(a, stream);
+        case 2: return launch_cfg<4, 1, 64, 64>(a, stream);
+        case 3: return launch_cfg<2, 2, 32, 32>(a, stream);
+        default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
+    }
+}

@@ -1,0 +1,265 @@
+// Small / boundary kernels of the UNet: conv_in (tiny Cin), conv_out (tiny Cout),
+// sinusoidal timestep embedding (K10) and the skinny GEMM used by the time /
+// added-condition MLPs and the batched time_emb_proj (M = UNet batch rows <= 64).
+// None of them matters for FLOPs; they exist so that the whole forward stays on
+// the device, asynchronous, with no host round trip.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// conv_in: 3x3 pad 1, Cin <= 8, NCHW latent (fp32 or fp16) -> halo-padded NHWC fp16.
+// Output row r reads latent sample (r % zB): the reference's torch.cat([zt]*2)
+// (latent_diffusion.py:153) is an index computation here (K13 eliminated).
+// w: [9*Cin][Cout] fp32 (k = tap*Cin + ci), bias [Cout] fp32.
+// ---------------------------------------------------------------------------
+template <typename TIN>
+__global__ void __launch_bounds__(256)
+conv_in_kernel(const TIN* __restrict__ z, half_t* __restrict__ out, const float* __restrict__ w,
+               const float* __restrict__ bias, int R, int zB, int Cin, int H, int W, int Cout) {
+    constexpr int TP = 16;                 // pixels per block
+    __shared__ float patch[TP][9 * 8];
+    const int r = blockIdx.y;
+    const int p0 = blockIdx.x * TP;
+    const int HW = H * W;
+    const int zb = r % zB;
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < TP * K; i += blockDim.x) {
+        const int tp = i / K, k = i - tp * K;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int p = p0 + tp;
+        float v = 0.f;
+        if (p < HW) {
+            const int y = p / W + tap / 3 - 1, x = p % W + tap % 3 - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = (float)z[((long)(zb * Cin + ci) * H + y) * W + x];
+        }
+        // the reference feeds the UNet an fp16 sample under autocast: round the input once
+        patch[tp][k] = (float)(half_t)v;
+    }
+    __syncthreads();
+    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+        float acc[TP];
+        const float b = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) acc[tp] = b;
+        for (int k = 0; k < K; ++k) {
+            const float wv = w[(long)k * Cout + co];
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp) acc[tp] += wv * patch[tp][k];
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+            const int p = p0 + tp;
+            if (p < HW) {
+                const int y = p / W, x = p - y * W;
+                out[((long)(r * (H + 2) + y + 1) * (W + 2) + x + 1) * Cout + co] = (half_t)acc[tp];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// conv_out: 3x3 pad 1, Cout <= 4, halo-padded NHWC fp16 -> NCHW (fp16 or fp32).
+// One wave per output pixel, lanes split K = 9*C in 8-channel chunks.
+// w: [Cout][9][C] fp16.
+// ---------------------------------------------------------------------------
+template <int CO, typename TOUT>
+__global__ void __launch_bounds__(256)
+conv_out_kernel(const half_t* __restrict__ x, TOUT* __restrict__ out, const half_t* __restrict__ w,
+                const float* __restrict__ bias, int R, int H, int W, int C, int cout_real) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)R * H * W;
+    if (pix >= total) return;
+    const int HW = H * W;
+    const int r = (int)(pix / HW), p = (int)(pix - (long)r * HW);
+    const int y = p / W, xq = p - y * W;
+    const int cpt = C / 8;                      // chunks per tap
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    for (int c = lane; c < 9 * cpt; c += 64) {
+        const int tap = c / cpt, cc = (c - tap * cpt) * 8;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const half8_t xv = *reinterpret_cast<const half8_t*>(
+            x + ((long)(r * (H + 2) + y + 1 + dy) * (W + 2) + xq + 1 + dx) * C + cc);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const half8_t wv = *reinterpret_cast<const half8_t*>(w + ((long)o * 9 + tap) * C + cc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[o] += (float)xv[k] * (float)wv[k];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s);
+    if (lane < cout_real) {
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) if (lane == o) v = acc[o];
+        v += bias ? bias[lane] : 0.f;
+        out[((long)(r * cout_real + lane) * H + y) * W + xq] = (TOUT)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos=True,
+// downscale_freq_shift=0): out[i][0:half] = cos(v_i * e_j), out[i][half:] = sin(v_i * e_j),
+// e_j = exp(-ln(10000) * j / half).  Values are rounded through fp16 like the
+// reference's `t_emb.to(dtype=sample.dtype)`.
+// vals: device pointer to `count` floats, or null -> use `scalar` for all.
+// ---------------------------------------------------------------------------
+__global__ void sinusoid_kernel(const float* __restrict__ vals, float scalar, float* __restrict__ out,
+                                int count, int dim, int out_ld, int out_off) {
+    const int i = blockIdx.x;
+    const int half_dim = dim / 2;
+    const float v = vals ? vals[i] : scalar;
+    for (int j = threadIdx.x; j < half_dim; j += blockDim.x) {
+        const float e = expf(-9.210340371976184f * (float)j / (float)half_dim);
+        const float arg = v * e;
+        out[(long)i * out_ld + out_off + j] = (float)(half_t)cosf(arg);
+        out[(long)i * out_ld + out_off + half_dim + j] = (float)(half_t)sinf(arg);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// skinny GEMM: out[m][n] = sum_k act(x[m][k]) * W[n][k] + bias[n] (+ addend[m or 0][n]),
+// x fp32 [M][K] (row stride ldx, or stride 0 = broadcast row), W fp16 [N][K], out fp32.
+// Each wave: MB rows x NB columns, lanes split K in 8-element chunks.
+// ---------------------------------------------------------------------------
+template <int MB, int NB>
+__global__ void __launch_bounds__(256)
+skinny_gemm_kernel(const float* __restrict__ x, int ldx, const half_t* __restrict__ w, const float* __restrict__ bias,
+                   const float* __restrict__ addend, int add_ld, float* __restrict__ out, int ldo,
+                   int M, int N, int K, int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wid) * NB;
+    const int m0 = blockIdx.y * MB;
+    if (n0 >= N) return;
+    float acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = 0.f;
+    for (int kc = lane * 8; kc < K; kc += 64 * 8) {
+        float xv[MB][8];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int m = min(m0 + i, M - 1);
+            const float4 a = *reinterpret_cast<const float4*>(x + (long)m * ldx + kc);
+            const float4 b = *reinterpret_cast<const float4*>(x + (long)m * ldx + kc + 4);
+            xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+            xv[i][4] = b.x; xv[i][5] = b.y; xv[i][6] = b.z; xv[i][7] = b.w;
+            if (silu_in) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[i][k] = silu_f(xv[i][k]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = min(n0 + j, N - 1);
+            const half8_t wv = *reinterpret_cast<const half8_t*>(w + (long)n * K + kc);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[i][j] += xv[i][k] * (float)wv[k];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) acc[i][j] += __shfl_xor(acc[i][j], s);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int m = m0 + i;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int n = n0 + j;
+                if (n >= N) continue;
+                float v = acc[i][j] + (bias ? bias[n] : 0.f);
+                if (addend) v += addend[(long)m * add_ld + n];
+                if (silu_out) v = silu_f(v);
+                out[(long)m * ldo + n] = v;
+            }
+        }
+    }
+}
+
+__global__ void f16_to_f32_rows_kernel(const half_t* __restrict__ in, float* __restrict__ out, int rows, int cols,
+                                       int out_ld, int out_off) {
+    const long n = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        out[(long)r * out_ld + out_off + c] = (float)in[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
+                     int R, int zB, int Cin, int H, int W, int Cout, void* stream) {
+    CFGPP_REQUIRE(Cin >= 1 && Cin <= 8, "conv_in: Cin=%d (<= 8)", Cin);
+    CFGPP_REQUIRE(z && out && w && R > 0 && zB > 0, "conv_in: bad args");
+    dim3 grid(cdiv((long)H * W, 16), R);
+    hipStream_t s = (hipStream_t)stream;
+    if (z_is_half)
+        hipLaunchKernelGGL(conv_in_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout);
+    else
+        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
+                      int R, int H, int W, int C, int Cout, void* stream) {
+    CFGPP_REQUIRE(Cout >= 1 && Cout <= 4 && C % 8 == 0, "conv_out: Cout=%d C=%d", Cout, C);
+    CFGPP_REQUIRE(x && out && w, "conv_out: null pointer");
+    const long total = (long)R * H * W;
+    dim3 grid(cdiv(total, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (out_is_half)
+        hipLaunchKernelGGL((conv_out_kernel<4, half_t>), grid, dim3(256), 0, s, (const half_t*)x, (half_t*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+    else
+        hipLaunchKernelGGL((conv_out_kernel<4, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_op_sinusoid(const float* vals, float scalar, float* out, int count, int dim, int out_ld, int out_off,
+                      void* stream) {
+    CFGPP_REQUIRE(out && count > 0 && dim % 2 == 0, "sinusoid: bad args");
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(count), dim3(128), 0, (hipStream_t)stream, vals, scalar, out, count, dim, out_ld, out_off);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_op_skinny_gemm(const float* x, int ldx, const void* w, const float* bias, const float* addend, int add_ld,
+                         float* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream) {
+    CFGPP_REQUIRE(x && w && out && M > 0 && N > 0 && K % 8 == 0, "skinny_gemm: bad args (K=%d)", K);
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 1) {
+        dim3 grid(cdiv(N, 4 * 2), 1);
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 2>), grid, dim3(256), 0, s, x, ldx, (const half_t*)w, bias, addend, add_ld, out, ldo, M, N, K, silu_in, silu_out);
+    } else {
+        dim3 grid(cdiv(N, 4 * 2), cdiv(M, 4));
+        hipLaunchKernelGGL((skinny_gemm_kernel<4, 2>), grid, dim3(256), 0, s, x, ldx, (const half_t*)w, bias, addend, add_ld, out, ldo, M, N, K, silu_in, silu_out);
+    }
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_op_f16_to_f32_rows(const void* in, float* out, int rows, int cols, int out_ld, int out_off, void* stream) {
+    hipLaunchKernelGGL(f16_to_f32_rows_kernel, dim3(cdiv((long)rows * cols, 256) > 1024 ? 1024 : cdiv((long)rows * cols, 256)),
+                       dim3(256), 0, (hipStream_t)stream, (const half_t*)in, out, rows, cols, out_ld, out_off);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,787 @@
+// UNet engine: the MI355X-native replacement of the reference's
+//     self.unet(z_in, t_in, encoder_hidden_states=c_embed[, added_cond_kwargs])['sample']
+// (latent_diffusion.py:146-156, latent_sdxl.py:170-183).
+//
+// Architecture follows diffusers-0.27.1 UNet2DConditionModel semantics for the
+// SD1.5 / SDXL configs: conv_in, time (+ text_time) embedding,
+// {ResnetBlock2D, Transformer2DModel} down / mid / up blocks with skip concat,
+// GroupNorm-SiLU-conv_out.  Weights are loaded by their diffusers state-dict keys
+// and repacked once into the layouts the kernels want; the forward is a static
+// launch plan (vector of closures) over preallocated, shape-keyed activation
+// buffers in halo-padded NHWC fp16 - no allocation, no host sync, one stream.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cfgpp.h"
+#include "igemm.h"
+
+namespace {
+
+struct HostParam {
+    std::vector<long> shape;
+    std::vector<half_t> h;     // matrices / conv kernels
+    std::vector<float> f;      // 1-D params (bias, norm) and conv_in
+    bool is_matrix = false;
+    bool loaded = false;
+    long numel() const { long n = 1; for (long s : shape) n *= s; return n; }
+};
+
+struct Tensor {   // halo-padded NHWC fp16 activation
+    half_t* p = nullptr;
+    int H = 0, W = 0, C = 0;
+};
+
+using Op = std::function<int(hipStream_t, int /*rows*/)>;
+
+}  // namespace
+
+struct cfgpp_unet {
+    cfgpp_unet_config cfg;
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, HostParam> params;
+    std::vector<void*> allocs;
+    double dev_bytes = 0;
+    double macs_per_row = 0;        // conv/linear MACs per batch row per forward (excl. cross K/V)
+    double attn_macs_per_row = 0;
+
+    std::vector<Op> plan;           // forward
+    std::vector<Op> ctx_plan;       // set_context (cross-attention K/V, added-condition embedding)
+
+    // activation pool, keyed by shape (halo stays zero for ever)
+    std::map<std::tuple<int, int, int>, std::vector<half_t*>> pool;
+
+    // forward-time inputs (pointers patched per call)
+    const void* in_z = nullptr; int in_z_half = 0; int in_z_rows = 0; float in_t = 0.f; void* out_eps = nullptr;
+    // context inputs
+    const half_t* ctx_ehs = nullptr; int ctx_rows = 0; int ctx_tokens = 77;
+    const half_t* ctx_text = nullptr; const float* ctx_tids = nullptr; int ctx_cond_rows = 0;
+    bool ctx_set = false;
+
+    // time-embedding scratch
+    float* d_sin_t = nullptr; float* d_emb_h = nullptr; float* d_emb_t = nullptr; float* d_emb = nullptr;
+    float* d_temb_all = nullptr; int temb_total = 0;
+    float* d_add_in = nullptr; float* d_add_h = nullptr; float* d_aug = nullptr;
+    float* d_gn_stats = nullptr;
+
+    // transformer scratch (token-major)
+    half_t *tok_x = nullptr, *tok_ln = nullptr, *tok_attn = nullptr, *tok_ff = nullptr;
+    // head-major Q / K / V^T scratch, ONE SET PER LEVEL: a level has fixed (heads, tokens, d), so the
+    // zero padding of the head dim (d..dp) is never overwritten by a differently shaped user.
+    half_t *hq[4] = {nullptr, nullptr, nullptr, nullptr}, *hk[4] = {nullptr, nullptr, nullptr, nullptr},
+           *hvt[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    void* dmalloc(size_t bytes, bool zero = true) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (zero) hipMemset(p, 0, bytes);
+        allocs.push_back(p);
+        dev_bytes += (double)bytes;
+        return p;
+    }
+    Tensor acq(int H, int W, int C) {
+        auto key = std::make_tuple(H, W, C);
+        auto& fl = pool[key];
+        Tensor t; t.H = H; t.W = W; t.C = C;
+        if (!fl.empty()) { t.p = fl.back(); fl.pop_back(); return t; }
+        t.p = (half_t*)dmalloc((size_t)cfg.max_rows * (H + 2) * (W + 2) * C * sizeof(half_t));
+        return t;
+    }
+    void rel(const Tensor& t) { if (t.p) pool[std::make_tuple(t.H, t.W, t.C)].push_back(t.p); }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// expected parameter table
+// ---------------------------------------------------------------------------
+void expect(cfgpp_unet* u, const std::string& key, std::vector<long> shape, bool matrix) {
+    HostParam hp; hp.shape = std::move(shape); hp.is_matrix = matrix;
+    u->params[key] = std::move(hp);
+}
+void expect_linear(cfgpp_unet* u, const std::string& p, long out, long in, bool bias = true) {
+    expect(u, p + ".weight", {out, in}, true);
+    if (bias) expect(u, p + ".bias", {out}, false);
+}
+void expect_conv(cfgpp_unet* u, const std::string& p, long out, long in, int k) {
+    expect(u, p + ".weight", {out, in, k, k}, true);
+    expect(u, p + ".bias", {out}, false);
+}
+void expect_norm(cfgpp_unet* u, const std::string& p, long c) {
+    expect(u, p + ".weight", {c}, false);
+    expect(u, p + ".bias", {c}, false);
+}
+void expect_resnet(cfgpp_unet* u, const std::string& p, long cin, long cout, long temb) {
+    expect_norm(u, p + ".norm1", cin);
+    expect_conv(u, p + ".conv1", cout, cin, 3);
+    expect_linear(u, p + ".time_emb_proj", cout, temb);
+    expect_norm(u, p + ".norm2", cout);
+    expect_conv(u, p + ".conv2", cout, cout, 3);
+    if (cin != cout) expect_conv(u, p + ".conv_shortcut", cout, cin, 1);
+}
+void expect_transformer(cfgpp_unet* u, const std::string& p, long c, int depth, long cross) {
+    expect_norm(u, p + ".norm", c);
+    // proj_in/out: conv1x1 [c,c,1,1] (SD1.5) or linear [c,c] (SDXL): accept either (numel equal)
+    expect(u, p + ".proj_in.weight", {c, c}, true);  expect(u, p + ".proj_in.bias", {c}, false);
+    expect(u, p + ".proj_out.weight", {c, c}, true); expect(u, p + ".proj_out.bias", {c}, false);
+    for (int k = 0; k < depth; ++k) {
+        const std::string b = p + ".transformer_blocks." + std::to_string(k);
+        expect_norm(u, b + ".norm1", c); expect_norm(u, b + ".norm2", c); expect_norm(u, b + ".norm3", c);
+        expect_linear(u, b + ".attn1.to_q", c, c, false); expect_linear(u, b + ".attn1.to_k", c, c, false);
+        expect_linear(u, b + ".attn1.to_v", c, c, false); expect_linear(u, b + ".attn1.to_out.0", c, c, true);
+        expect_linear(u, b + ".attn2.to_q", c, c, false); expect_linear(u, b + ".attn2.to_k", c, cross, false);
+        expect_linear(u, b + ".attn2.to_v", c, cross, false); expect_linear(u, b + ".attn2.to_out.0", c, c, true);
+        expect_linear(u, b + ".ff.net.0.proj", 8 * c, c, true);
+        expect_linear(u, b + ".ff.net.2", c, 4 * c, true);
+    }
+}
+
+void build_param_table(cfgpp_unet* u) {
+    const cfgpp_unet_config& c = u->cfg;
+    const int L = c.num_levels;
+    const long c0 = c.block_out_channels[0], temb = 4 * c0;
+    expect_conv(u, "conv_in", c0, c.in_channels, 3);
+    expect_linear(u, "time_embedding.linear_1", temb, c0);
+    expect_linear(u, "time_embedding.linear_2", temb, temb);
+    if (c.addition_embed) {
+        const long in = (long)c.addition_time_embed_dim * 6 + c.addition_pooled_dim;
+        expect_linear(u, "add_embedding.linear_1", temb, in);
+        expect_linear(u, "add_embedding.linear_2", temb, temb);
+    }
+    long ch = c0;
+    for (int i = 0; i < L; ++i) {
+        const long co = c.block_out_channels[i];
+        const std::string p = "down_blocks." + std::to_string(i);
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            expect_resnet(u, p + ".resnets." + std::to_string(j), ch, co, temb);
+            if (c.level_has_attn[i])
+                expect_transformer(u, p + ".attentions." + std::to_string(j), co, c.transformer_depth[i], c.cross_attention_dim);
+            ch = co;
+        }
+        if (i != L - 1) expect_conv(u, p + ".downsamplers.0.conv", co, co, 3);
+    }
+    const long cm = c.block_out_channels[L - 1];
+    expect_resnet(u, "mid_block.resnets.0", cm, cm, temb);
+    expect_transformer(u, "mid_block.attentions.0", cm, c.transformer_depth[L - 1], c.cross_attention_dim);
+    expect_resnet(u, "mid_block.resnets.1", cm, cm, temb);
+    // up blocks (diffusers: reversed channels; layers_per_block+1 resnets each)
+    long prev = cm;
+    for (int i = 0; i < L; ++i) {
+        const int lvl = L - 1 - i;
+        const long co = c.block_out_channels[lvl];
+        const long cin_lvl = c.block_out_channels[std::max(lvl - 1, 0)];
+        const std::string p = "up_blocks." + std::to_string(i);
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            const long skip = (j == c.layers_per_block) ? cin_lvl : co;
+            const long rin = (j == 0 ? prev : co) + skip;
+            expect_resnet(u, p + ".resnets." + std::to_string(j), rin, co, temb);
+            if (c.level_has_attn[lvl])
+                expect_transformer(u, p + ".attentions." + std::to_string(j), co, c.transformer_depth[lvl], c.cross_attention_dim);
+        }
+        if (i != L - 1) expect_conv(u, p + ".upsamplers.0.conv", co, co, 3);
+        prev = co;
+    }
+    expect_norm(u, "conv_norm_out", c0);
+    expect_conv(u, "conv_out", c.out_channels, c0, 3);
+}
+
+// ---------------------------------------------------------------------------
+// weight repacking (host) + upload
+// ---------------------------------------------------------------------------
+struct Builder {
+    cfgpp_unet* u;
+    bool ok = true;
+    std::string err;
+
+    HostParam* get(const std::string& key) {
+        auto it = u->params.find(key);
+        if (it == u->params.end() || !it->second.loaded) { ok = false; err = "missing parameter " + key; return nullptr; }
+        return &it->second;
+    }
+    template <typename T>
+    T* upload(const std::vector<T>& v) {
+        T* d = (T*)u->dmalloc(v.size() * sizeof(T), false);
+        if (!d) { ok = false; err = "hipMalloc failed"; return nullptr; }
+        if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { ok = false; err = "hipMemcpy failed"; }
+        return d;
+    }
+    void drop(const std::string& key) { auto& p = u->params[key]; std::vector<half_t>().swap(p.h); std::vector<float>().swap(p.f); }
+
+    float* f32(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        float* d = upload(p->f); drop(key); return d;
+    }
+    // [N][K] as is (linear, or conv1x1 OIHW)
+    half_t* linear(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        half_t* d = upload(p->h); drop(key); return d;
+    }
+    // OIHW -> [O][kh*kw][I]
+    half_t* conv3(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        const long O = p->shape[0], I = p->shape[1];
+        std::vector<half_t> r((size_t)O * 9 * I);
+        for (long o = 0; o < O; ++o)
+            for (long i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) r[((size_t)o * 9 + t) * I + i] = p->h[((size_t)o * I + i) * 9 + t];
+        half_t* d = upload(r); drop(key); return d;
+    }
+    // concat rows of several [n_i][K] matrices
+    half_t* concat(const std::vector<std::string>& keys) {
+        std::vector<half_t> r;
+        for (auto& k : keys) { HostParam* p = get(k); if (!p) return nullptr; r.insert(r.end(), p->h.begin(), p->h.end()); }
+        half_t* d = upload(r);
+        for (auto& k : keys) drop(k);
+        return d;
+    }
+    // GEGLU packing: within every 64 packed rows, [0,32) value rows f, [32,64) gate rows 4C+f
+    void geglu(const std::string& pfx, long C, half_t** w, float** b) {
+        HostParam* pw = get(pfx + ".weight"); HostParam* pb = get(pfx + ".bias");
+        if (!pw || !pb) return;
+        const long F = 4 * C;
+        std::vector<half_t> rw((size_t)2 * F * C); std::vector<float> rb((size_t)2 * F);
+        for (long f = 0; f < F; ++f) {
+            const long pv = (f / 32) * 64 + (f % 32), pg = pv + 32;
+            std::memcpy(&rw[(size_t)pv * C], &pw->h[(size_t)f * C], C * sizeof(half_t));
+            std::memcpy(&rw[(size_t)pg * C], &pw->h[(size_t)(F + f) * C], C * sizeof(half_t));
+            rb[pv] = pb->f[f]; rb[pg] = pb->f[F + f];
+        }
+        *w = upload(rw); *b = upload(rb);
+        drop(pfx + ".weight"); drop(pfx + ".bias");
+    }
+};
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// generic igemm op helpers ----------------------------------------------------
+IGemmArgs base_args() {
+    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; return a;
+}
+
+struct Plan {
+    cfgpp_unet* u;
+    Builder* B;
+    std::vector<Op>* ops;
+
+    // conv3x3 on padded NHWC.  amode 1 normal, 2 stride-2 (src is 2H x 2W), 3 upsample (src is H/2 x W/2)
+    void conv3x3(const Tensor& src, const Tensor& dst, const half_t* w, const float* bias, int amode,
+                 const float* temb, int temb_ld, const Tensor* resid) {
+        IGemmArgs a = base_args();
+        a.a0 = src.p; a.C0 = src.C; a.taps = 9; a.amode = amode; a.H = dst.H; a.W = dst.W;
+        a.w = w; a.N = dst.C; a.K = 9 * src.C; a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
+        a.rows_per_batch = dst.H * dst.W;
+        if (resid) { a.resid = resid->p; a.rmode = 1; a.rld = resid->C; }
+        a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * 9.0 * src.C;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+    }
+    // 1x1 conv over (src0 || src1) padded -> padded
+    void conv1x1(const Tensor& s0, const Tensor* s1, const Tensor& dst, const half_t* w, const float* bias) {
+        IGemmArgs a = base_args();
+        a.a0 = s0.p; a.C0 = s0.C; if (s1) { a.a1 = s1->p; a.C1 = s1->C; }
+        a.amode = 1; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = a.C0 + a.C1; a.bias = bias;
+        a.rows_per_batch = dst.H * dst.W; a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * a.K;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+    }
+    // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
+    void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
+                int tokens, int epi = EPI_STORE) {
+        IGemmArgs a = base_args();
+        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias;
+        a.resid = resid; a.rmode = 0; a.rld = N; a.out = out; a.omode = 0;
+        a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
+        u->macs_per_row += (double)tokens * N * K;
+        ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+    }
+    // tokens -> padded NHWC with residual from a padded tensor (Transformer2D proj_out)
+    void linear_to_padded(const half_t* A, int K, const Tensor& dst, const half_t* w, const float* bias, const Tensor& resid) {
+        IGemmArgs a = base_args();
+        a.a0 = A; a.C0 = K; a.amode = 0; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = K; a.bias = bias;
+        a.resid = resid.p; a.rmode = 1; a.rld = resid.C; a.out = dst.p; a.omode = 1; a.old = dst.C;
+        a.epi = EPI_STORE; a.rows_per_batch = dst.H * dst.W;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * K;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+    }
+    // projection into head-major buffers
+    void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
+               half_t* q, half_t* k, half_t* vt, int q_tok_pad, int tok_pad, bool count = true) {
+        IGemmArgs a = base_args();
+        const int d = C / nheads;
+        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.epi = EPI_HEADS;
+        a.rows_per_batch = tokens; a.hq = q; a.hk = k; a.hvt = vt; a.part0 = part0; a.part_width = C;
+        a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
+        if (count) u->macs_per_row += (double)tokens * N * K;
+        ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+    }
+    void groupnorm(const Tensor& s0, const Tensor* s1, half_t* dst, bool dst_padded, const float* g, const float* b,
+                   float eps, bool silu) {
+        cfgpp_unet* uu = u;
+        const half_t* p0 = s0.p; const half_t* p1 = s1 ? s1->p : nullptr;
+        const int H = s0.H, W = s0.W, C0 = s0.C, C1 = s1 ? s1->C : 0, G = u->cfg.norm_groups;
+        ops->push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_groupnorm(p0, p1, dst, g, b, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
+                                      dst_padded ? 1 : 0, s);
+        });
+    }
+    void layernorm(const half_t* x, half_t* y, const float* g, const float* b, int tokens, int C) {
+        ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_layernorm(x, y, g, b, (long)rows * tokens, C, 1e-5f, s); });
+    }
+    void attention(const half_t* q, const half_t* k, const half_t* vt, half_t* o, int nheads, int d, int nq, int nk,
+                   int q_tok_pad, int k_tok_pad) {
+        u->attn_macs_per_row += 2.0 * (double)nheads * nq * nk * d;
+        ops->push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_attention(q, k, vt, o, rows, nheads, d, nq, nk, q_tok_pad, k_tok_pad, s);
+        });
+    }
+};
+
+struct ResW {
+    float *n1g, *n1b, *n2g, *n2b, *b1, *b2, *bsc;
+    half_t *w1, *w2, *wsc;
+    int temb_off;   // column offset in temb_all
+    int cin, cout;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+cfgpp_unet* cfgpp_unet_create(const cfgpp_unet_config* cfg, int device_id) {
+    if (!cfg) { cfgpp_set_error("unet_create: null config"); return nullptr; }
+    if (cfg->num_levels < 1 || cfg->num_levels > 4 || cfg->layers_per_block < 1 || cfg->max_rows < 1) {
+        cfgpp_set_error("unet_create: bad config"); return nullptr;
+    }
+    for (int i = 0; i < cfg->num_levels; ++i) {
+        const int c = cfg->block_out_channels[i];
+        if (c % 64 != 0 || c % cfg->norm_groups != 0) { cfgpp_set_error("unet_create: channels %d must be a multiple of 64 and of norm_groups", c); return nullptr; }
+        if (cfg->level_has_attn[i]) {
+            const int d = c / cfg->num_heads[i];
+            if (c % cfg->num_heads[i] != 0 || d % 4 != 0 || d > 160) { cfgpp_set_error("unet_create: head dim %d unsupported", d); return nullptr; }
+        }
+    }
+    if (cfg->cross_attention_dim % 64 != 0) { cfgpp_set_error("unet_create: cross_attention_dim must be a multiple of 64"); return nullptr; }
+    if ((cfg->sample_h % (1 << (cfg->num_levels - 1))) || (cfg->sample_w % (1 << (cfg->num_levels - 1)))) {
+        cfgpp_set_error("unet_create: sample size must be divisible by 2^(levels-1)"); return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device_id) {
+        cfgpp_set_error("unet_create: no HIP device %d (found %d) - the HIP path has no CPU fallback", device_id, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) { cfgpp_set_error("unet_create: hipSetDevice failed"); return nullptr; }
+    cfgpp_unet* u = new cfgpp_unet();
+    u->cfg = *cfg; u->device = device_id;
+    build_param_table(u);
+    return u;
+}
+
+void cfgpp_unet_destroy(cfgpp_unet* u) {
+    if (!u) return;
+    for (void* p : u->allocs) hipFree(p);
+    delete u;
+}
+
+int cfgpp_unet_load_tensor(cfgpp_unet* u, const char* key, const void* host, int dtype, const long* shape, int ndim) {
+    CFGPP_REQUIRE(u && key && host && shape, "load_tensor: null argument");
+    CFGPP_REQUIRE(!u->finalized, "load_tensor: context already finalized");
+    auto it = u->params.find(key);
+    if (it == u->params.end()) { cfgpp_set_error("load_tensor: unknown key %s", key); return -3; }
+    HostParam& p = it->second;
+    long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i];
+    CFGPP_REQUIRE(n == p.numel(), "load_tensor: %s has %ld elements, expected %ld", key, n, p.numel());
+    if (ndim == 4) { p.shape.assign(shape, shape + 4); }   // keep OIHW (conv1x1 vs linear both fine)
+    if (p.is_matrix && !(std::string(key) == "conv_in.weight")) {
+        p.h.resize(n);
+        if (dtype == 0) { const float* s = (const float*)host; for (long i = 0; i < n; ++i) p.h[i] = (half_t)s[i]; }
+        else std::memcpy(p.h.data(), host, n * sizeof(half_t));
+    } else {
+        p.f.resize(n);
+        if (dtype == 0) std::memcpy(p.f.data(), host, n * sizeof(float));
+        else { const half_t* s = (const half_t*)host; for (long i = 0; i < n; ++i) p.f[i] = (float)s[i]; }
+    }
+    p.loaded = true;
+    return 0;
+}
+
+int cfgpp_unet_missing(cfgpp_unet* u) {
+    if (!u) return -1;
+    int n = 0; std::string names;
+    for (auto& kv : u->params) if (!kv.second.loaded) { if (n < 8) names += kv.first + " "; ++n; }
+    if (n) cfgpp_set_error("missing %d parameters: %s...", n, names.c_str());
+    return n;
+}
+
+int cfgpp_unet_finalize(cfgpp_unet* u) {
+    CFGPP_REQUIRE(u, "finalize: null");
+    CFGPP_REQUIRE(!u->finalized, "finalize: already finalized");
+    if (cfgpp_unet_missing(u) != 0) { const std::string m = cfgpp_last_error(); cfgpp_set_error("finalize: %s", m.c_str()); return -2; }
+    CFGPP_HIP_CHECK(hipSetDevice(u->device));
+    const cfgpp_unet_config& c = u->cfg;
+    const int L = c.num_levels, R = c.max_rows;
+    const int c0 = c.block_out_channels[0], temb_dim = 4 * c0;
+    Builder B{u};
+    Plan P{u, &B, &u->plan};
+    Plan PC{u, &B, &u->ctx_plan};
+
+    // ---- scratch sizing ----
+    long max_tok_c = 0, max_ff = 0;
+    {
+        int H = c.sample_h, W = c.sample_w;
+        for (int i = 0; i < L; ++i) {
+            const long C = c.block_out_channels[i];
+            if (c.level_has_attn[i] || i == L - 1) {
+                const long tok = (long)H * W;
+                const int d = (int)(C / c.num_heads[i]), dp = round_up(d, 32);
+                max_tok_c = std::max(max_tok_c, tok * C);
+                max_ff = std::max(max_ff, tok * 4 * C);
+                u->hq[i] = (half_t*)u->dmalloc((size_t)R * c.num_heads[i] * round_up((int)tok, 128) * dp * 2);
+                u->hk[i] = (half_t*)u->dmalloc((size_t)R * c.num_heads[i] * round_up((int)tok, 128) * dp * 2);
+                u->hvt[i] = (half_t*)u->dmalloc((size_t)R * c.num_heads[i] * dp * round_up((int)tok, 64) * 2);
+                CFGPP_REQUIRE(u->hq[i] && u->hk[i] && u->hvt[i], "finalize: hipMalloc failed");
+            }
+            if (i != L - 1) { H /= 2; W /= 2; }
+        }
+    }
+    u->tok_x = (half_t*)u->dmalloc((size_t)R * max_tok_c * 2);
+    u->tok_ln = (half_t*)u->dmalloc((size_t)R * max_tok_c * 2);
+    u->tok_attn = (half_t*)u->dmalloc((size_t)R * max_tok_c * 2);
+    u->tok_ff = (half_t*)u->dmalloc((size_t)R * max_ff * 2);
+    u->d_gn_stats = (float*)u->dmalloc((size_t)R * 64 * 2 * sizeof(float));
+    u->d_sin_t = (float*)u->dmalloc((size_t)c0 * sizeof(float));
+    u->d_emb_h = (float*)u->dmalloc((size_t)temb_dim * sizeof(float));
+    u->d_emb_t = (float*)u->dmalloc((size_t)temb_dim * sizeof(float));
+    u->d_emb = (float*)u->dmalloc((size_t)R * temb_dim * sizeof(float));
+    CFGPP_REQUIRE(u->tok_x && u->tok_ln && u->tok_attn && u->tok_ff, "finalize: hipMalloc failed");
+
+    // ---- collect every resnet's time_emb_proj into one [sumC][temb] matrix ----
+    std::vector<std::string> res_names;
+    {
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < c.layers_per_block; ++j) res_names.push_back("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+        res_names.push_back("mid_block.resnets.0"); res_names.push_back("mid_block.resnets.1");
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < c.layers_per_block + 1; ++j) res_names.push_back("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+    }
+    std::map<std::string, int> temb_off;
+    half_t* w_temb_all = nullptr; float* b_temb_all = nullptr;
+    {
+        std::vector<half_t> wa; std::vector<float> ba; int off = 0;
+        for (auto& rn : res_names) {
+            HostParam* pw = B.get(rn + ".time_emb_proj.weight"); HostParam* pb = B.get(rn + ".time_emb_proj.bias");
+            CFGPP_REQUIRE(pw && pb, "finalize: %s", B.err.c_str());
+            temb_off[rn] = off; off += (int)pw->shape[0];
+            wa.insert(wa.end(), pw->h.begin(), pw->h.end()); ba.insert(ba.end(), pb->f.begin(), pb->f.end());
+            B.drop(rn + ".time_emb_proj.weight"); B.drop(rn + ".time_emb_proj.bias");
+        }
+        u->temb_total = off;
+        w_temb_all = B.upload(wa); b_temb_all = B.upload(ba);
+        u->d_temb_all = (float*)u->dmalloc((size_t)R * off * sizeof(float));
+    }
+    const bool per_row_temb = c.addition_embed != 0;
+    const int temb_ld = per_row_temb ? u->temb_total : 0;
+
+    // ---- time embedding ops (head of the forward plan) ----
+    {
+        half_t* w1 = B.linear("time_embedding.linear_1.weight"); float* b1 = B.f32("time_embedding.linear_1.bias");
+        half_t* w2 = B.linear("time_embedding.linear_2.weight"); float* b2 = B.f32("time_embedding.linear_2.bias");
+        cfgpp_unet* uu = u;
+        u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_sinusoid(nullptr, uu->in_t, uu->d_sin_t, 1, c0, c0, 0, s); });
+        u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_skinny_gemm(uu->d_sin_t, c0, w1, b1, nullptr, 0, uu->d_emb_h, temb_dim, 1, temb_dim, c0, 0, 1, s); });
+        if (per_row_temb) {
+            // emb[r] = linear_2(h) + aug[r or 0]
+            u->plan.push_back([=](hipStream_t s, int rows) {
+                const int add_ld = uu->ctx_cond_rows == 1 ? 0 : temb_dim;
+                return cfgpp_op_skinny_gemm(uu->d_emb_h, 0, w2, b2, uu->d_aug, add_ld, uu->d_emb, temb_dim, rows, temb_dim, temb_dim, 0, 0, s);
+            });
+            u->plan.push_back([=](hipStream_t s, int rows) {
+                return cfgpp_op_skinny_gemm(uu->d_emb, temb_dim, w_temb_all, b_temb_all, nullptr, 0, uu->d_temb_all, uu->temb_total, rows, uu->temb_total, temb_dim, 1, 0, s);
+            });
+        } else {
+            u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_skinny_gemm(uu->d_emb_h, temb_dim, w2, b2, nullptr, 0, uu->d_emb_t, temb_dim, 1, temb_dim, temb_dim, 0, 0, s); });
+            u->plan.push_back([=](hipStream_t s, int) {
+                return cfgpp_op_skinny_gemm(uu->d_emb_t, temb_dim, w_temb_all, b_temb_all, nullptr, 0, uu->d_temb_all, uu->temb_total, 1, uu->temb_total, temb_dim, 1, 0, s);
+            });
+        }
+        if (c.addition_embed) {
+            const int tdim = c.addition_time_embed_dim, pooled = c.addition_pooled_dim, in = 6 * tdim + pooled;
+            half_t* aw1 = B.linear("add_embedding.linear_1.weight"); float* ab1 = B.f32("add_embedding.linear_1.bias");
+            half_t* aw2 = B.linear("add_embedding.linear_2.weight"); float* ab2 = B.f32("add_embedding.linear_2.bias");
+            u->d_add_in = (float*)u->dmalloc((size_t)R * in * sizeof(float));
+            u->d_add_h = (float*)u->dmalloc((size_t)R * temb_dim * sizeof(float));
+            u->d_aug = (float*)u->dmalloc((size_t)R * temb_dim * sizeof(float));
+            // add_in[r] = [text_embeds[r] | sinusoid(time_ids[r][0..5])]
+            u->ctx_plan.push_back([=](hipStream_t s, int) { return cfgpp_op_f16_to_f32_rows(uu->ctx_text, uu->d_add_in, uu->ctx_cond_rows, pooled, in, 0, s); });
+            u->ctx_plan.push_back([=](hipStream_t s, int) {
+                // 6*cond_rows values, each -> tdim wide, laid out contiguously after the pooled part of its row
+                for (int r = 0; r < uu->ctx_cond_rows; ++r) {
+                    int e = cfgpp_op_sinusoid(uu->ctx_tids + (long)r * 6, 0.f, uu->d_add_in + (long)r * in + pooled, 6, tdim, tdim, 0, s);
+                    if (e) return e;
+                }
+                return 0;
+            });
+            u->ctx_plan.push_back([=](hipStream_t s, int) { return cfgpp_op_skinny_gemm(uu->d_add_in, in, aw1, ab1, nullptr, 0, uu->d_add_h, temb_dim, uu->ctx_cond_rows, temb_dim, in, 0, 1, s); });
+            u->ctx_plan.push_back([=](hipStream_t s, int) { return cfgpp_op_skinny_gemm(uu->d_add_h, temb_dim, aw2, ab2, nullptr, 0, uu->d_aug, temb_dim, uu->ctx_cond_rows, temb_dim, temb_dim, 0, 0, s); });
+        }
+    }
+
+    // ---- layer builders ----
+    auto load_res = [&](const std::string& p, int cin, int cout) {
+        ResW w{}; w.cin = cin; w.cout = cout;
+        w.n1g = B.f32(p + ".norm1.weight"); w.n1b = B.f32(p + ".norm1.bias");
+        w.w1 = B.conv3(p + ".conv1.weight"); w.b1 = B.f32(p + ".conv1.bias");
+        w.n2g = B.f32(p + ".norm2.weight"); w.n2b = B.f32(p + ".norm2.bias");
+        w.w2 = B.conv3(p + ".conv2.weight"); w.b2 = B.f32(p + ".conv2.bias");
+        if (cin != cout) { w.wsc = B.linear(p + ".conv_shortcut.weight"); w.bsc = B.f32(p + ".conv_shortcut.bias"); }
+        w.temb_off = temb_off[p];
+        return w;
+    };
+    // x0 (|| x1) -> new tensor
+    auto resblock = [&](const std::string& p, const Tensor& x0, const Tensor* x1, int cout) {
+        const int cin = x0.C + (x1 ? x1->C : 0);
+        ResW w = load_res(p, cin, cout);
+        Tensor g1 = u->acq(x0.H, x0.W, cin);
+        P.groupnorm(x0, x1, g1.p, true, w.n1g, w.n1b, 1e-5f, true);
+        Tensor h1 = u->acq(x0.H, x0.W, cout);
+        P.conv3x3(g1, h1, w.w1, w.b1, 1, u->d_temb_all + w.temb_off, temb_ld, nullptr);
+        u->rel(g1);
+        Tensor g2 = u->acq(x0.H, x0.W, cout);
+        P.groupnorm(h1, nullptr, g2.p, true, w.n2g, w.n2b, 1e-5f, true);
+        u->rel(h1);
+        Tensor out = u->acq(x0.H, x0.W, cout);
+        if (cin != cout) {
+            Tensor sc = u->acq(x0.H, x0.W, cout);
+            P.conv1x1(x0, x1, sc, w.wsc, w.bsc);
+            P.conv3x3(g2, out, w.w2, w.b2, 1, nullptr, 0, &sc);
+            u->rel(sc);
+        } else {
+            P.conv3x3(g2, out, w.w2, w.b2, 1, nullptr, 0, &x0);
+        }
+        u->rel(g2);
+        return out;
+    };
+    int cross_block_counter = 0;
+    auto transformer = [&](const std::string& p, const Tensor& x, int depth, int nheads, int lvl) {
+        half_t* const HQ = u->hq[lvl]; half_t* const HK = u->hk[lvl]; half_t* const HVT = u->hvt[lvl];
+        const int C = x.C, tok = x.H * x.W, d = C / nheads, dp = round_up(d, 32);
+        const int q_pad = round_up(tok, 128), k_pad = round_up(tok, 64);
+        const int ck_pad = round_up(u->ctx_tokens, 64);
+        float* ng = B.f32(p + ".norm.weight"); float* nb = B.f32(p + ".norm.bias");
+        half_t* wpi = B.linear(p + ".proj_in.weight"); float* bpi = B.f32(p + ".proj_in.bias");
+        half_t* wpo = B.linear(p + ".proj_out.weight"); float* bpo = B.f32(p + ".proj_out.bias");
+        P.groupnorm(x, nullptr, u->tok_ln, false, ng, nb, 1e-6f, false);
+        P.linear(u->tok_ln, C, u->tok_x, C, wpi, bpi, nullptr, tok);
+        for (int k = 0; k < depth; ++k) {
+            const std::string b = p + ".transformer_blocks." + std::to_string(k);
+            float* l1g = B.f32(b + ".norm1.weight"); float* l1b = B.f32(b + ".norm1.bias");
+            float* l2g = B.f32(b + ".norm2.weight"); float* l2b = B.f32(b + ".norm2.bias");
+            float* l3g = B.f32(b + ".norm3.weight"); float* l3b = B.f32(b + ".norm3.bias");
+            half_t* wqkv = B.concat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"});
+            half_t* wo1 = B.linear(b + ".attn1.to_out.0.weight"); float* bo1 = B.f32(b + ".attn1.to_out.0.bias");
+            half_t* wq2 = B.linear(b + ".attn2.to_q.weight");
+            half_t* wkv2 = B.concat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"});
+            half_t* wo2 = B.linear(b + ".attn2.to_out.0.weight"); float* bo2 = B.f32(b + ".attn2.to_out.0.bias");
+            half_t* wff1 = nullptr; float* bff1 = nullptr; B.geglu(b + ".ff.net.0.proj", C, &wff1, &bff1);
+            half_t* wff2 = B.linear(b + ".ff.net.2.weight"); float* bff2 = B.f32(b + ".ff.net.2.bias");
+            // persistent cross-attention K / V^T of this block (filled by set_context)
+            half_t* ck = (half_t*)u->dmalloc((size_t)R * nheads * ck_pad * dp * 2);
+            half_t* cvt = (half_t*)u->dmalloc((size_t)R * nheads * dp * ck_pad * 2);
+            {
+                cfgpp_unet* uu = u; const int Dc = c.cross_attention_dim; const int ckp = ck_pad;
+                IGemmArgs a = base_args();
+                a.C0 = Dc; a.amode = 0; a.w = wkv2; a.N = 2 * C; a.K = Dc; a.epi = EPI_HEADS;
+                a.hq = nullptr; a.hk = ck; a.hvt = cvt; a.part0 = 1; a.part_width = C; a.head_dim = d; a.head_dim_pad = dp;
+                a.heads = nheads; a.tok_pad = ckp; a.q_tok_pad = ckp;
+                u->ctx_plan.push_back([a, uu](hipStream_t s, int) mutable {
+                    IGemmArgs b2 = a; b2.a0 = uu->ctx_ehs; b2.rows_per_batch = uu->ctx_tokens; b2.M = uu->ctx_rows * uu->ctx_tokens;
+                    return igemm_launch(b2, s);
+                });
+            }
+            ++cross_block_counter;
+            // self-attention
+            P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
+            P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
+            P.attention(HQ, HK, HVT, u->tok_attn, nheads, d, tok, tok, q_pad, k_pad);
+            P.linear(u->tok_attn, C, u->tok_x, C, wo1, bo1, u->tok_x, tok);
+            // cross-attention
+            P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
+            P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
+            {
+                cfgpp_unet* uu = u;
+                u->attn_macs_per_row += 2.0 * (double)nheads * tok * 77 * d;
+                half_t* hq = HQ; half_t* o = u->tok_attn;
+                u->plan.push_back([=](hipStream_t s, int rows) {
+                    return cfgpp_op_attention(hq, ck, cvt, o, rows, nheads, d, tok, uu->ctx_tokens, q_pad, ck_pad, s);
+                });
+            }
+            P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
+            // feed-forward (GEGLU)
+            P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
+            P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);
+            P.linear(u->tok_ff, 4 * C, u->tok_x, C, wff2, bff2, u->tok_x, tok);
+        }
+        Tensor out = u->acq(x.H, x.W, C);
+        P.linear_to_padded(u->tok_x, C, out, wpo, bpo, x);
+        return out;
+    };
+
+    // ---- conv_in ----
+    int H = c.sample_h, W = c.sample_w;
+    Tensor x = u->acq(H, W, c0);
+    {
+        HostParam* pw = B.get("conv_in.weight"); HostParam* pb = B.get("conv_in.bias");
+        CFGPP_REQUIRE(pw && pb, "finalize: %s", B.err.c_str());
+        const int Ci = c.in_channels;
+        std::vector<float> r((size_t)9 * Ci * c0);
+        for (int o = 0; o < c0; ++o) for (int i = 0; i < Ci; ++i) for (int t = 0; t < 9; ++t)
+            r[(size_t)(t * Ci + i) * c0 + o] = pw->f[((size_t)o * Ci + i) * 9 + t];
+        float* dw = B.upload(r); float* db = B.upload(pb->f);
+        cfgpp_unet* uu = u; half_t* xp = x.p; const int HH = H, WW = W;
+        u->plan.push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_conv_in(uu->in_z, uu->in_z_half, xp, dw, db, rows, uu->in_z_rows, Ci, HH, WW, c0, s);
+        });
+    }
+    std::vector<Tensor> skips; skips.push_back(x);
+    // ---- down ----
+    for (int i = 0; i < L; ++i) {
+        const int co = c.block_out_channels[i];
+        const std::string p = "down_blocks." + std::to_string(i);
+        for (int j = 0; j < c.layers_per_block; ++j) {
+            Tensor y = resblock(p + ".resnets." + std::to_string(j), x, nullptr, co);
+            if (c.level_has_attn[i]) {
+                Tensor z = transformer(p + ".attentions." + std::to_string(j), y, c.transformer_depth[i], c.num_heads[i], i);
+                u->rel(y); y = z;
+            }
+            x = y; skips.push_back(x);
+        }
+        if (i != L - 1) {
+            half_t* wd = B.conv3(p + ".downsamplers.0.conv.weight"); float* bd = B.f32(p + ".downsamplers.0.conv.bias");
+            H /= 2; W /= 2;
+            Tensor y = u->acq(H, W, co);
+            P.conv3x3(x, y, wd, bd, 2, nullptr, 0, nullptr);
+            x = y; skips.push_back(x);
+        }
+    }
+    // ---- mid ----
+    {
+        const int cm = c.block_out_channels[L - 1];
+        Tensor y = resblock("mid_block.resnets.0", x, nullptr, cm);          // x is also the last skip: keep it
+        Tensor z = transformer("mid_block.attentions.0", y, c.transformer_depth[L - 1], c.num_heads[L - 1], L - 1);
+        u->rel(y);
+        Tensor w = resblock("mid_block.resnets.1", z, nullptr, cm);
+        u->rel(z);
+        x = w;
+    }
+    // ---- up ----
+    for (int i = 0; i < L; ++i) {
+        const int lvl = L - 1 - i;
+        const int co = c.block_out_channels[lvl];
+        const std::string p = "up_blocks." + std::to_string(i);
+        for (int j = 0; j < c.layers_per_block + 1; ++j) {
+            Tensor skip = skips.back(); skips.pop_back();
+            Tensor y = resblock(p + ".resnets." + std::to_string(j), x, &skip, co);
+            u->rel(x); u->rel(skip);
+            if (c.level_has_attn[lvl]) {
+                Tensor z = transformer(p + ".attentions." + std::to_string(j), y, c.transformer_depth[lvl], c.num_heads[lvl], lvl);
+                u->rel(y); y = z;
+            }
+            x = y;
+        }
+        if (i != L - 1) {
+            half_t* wu = B.conv3(p + ".upsamplers.0.conv.weight"); float* bu = B.f32(p + ".upsamplers.0.conv.bias");
+            H *= 2; W *= 2;
+            Tensor y = u->acq(H, W, co);
+            P.conv3x3(x, y, wu, bu, 3, nullptr, 0, nullptr);
+            u->rel(x); x = y;
+        }
+    }
+    // ---- out ----
+    {
+        float* g = B.f32("conv_norm_out.weight"); float* b = B.f32("conv_norm_out.bias");
+        Tensor gn = u->acq(H, W, c0);
+        P.groupnorm(x, nullptr, gn.p, true, g, b, 1e-5f, true);
+        HostParam* pw = B.get("conv_out.weight"); float* bo = B.f32("conv_out.bias");
+        CFGPP_REQUIRE(pw, "finalize: %s", B.err.c_str());
+        const int Co = c.out_channels;
+        CFGPP_REQUIRE(Co <= 4, "finalize: out_channels %d > 4 unsupported", Co);
+        std::vector<half_t> r((size_t)Co * 9 * c0);
+        for (int o = 0; o < Co; ++o) for (int i = 0; i < c0; ++i) for (int t = 0; t < 9; ++t)
+            r[((size_t)o * 9 + t) * c0 + i] = pw->h[((size_t)o * c0 + i) * 9 + t];
+        half_t* dw = B.upload(r);
+        cfgpp_unet* uu = u; half_t* gp = gn.p; const int HH = H, WW = W;
+        u->macs_per_row += (double)H * W * Co * 9.0 * c0 + (double)c.sample_h * c.sample_w * c0 * 9.0 * c.in_channels;
+        u->plan.push_back([=](hipStream_t s, int rows) { return cfgpp_op_conv_out(gp, uu->out_eps, 1, dw, bo, rows, HH, WW, c0, Co, s); });
+    }
+    CFGPP_REQUIRE(B.ok, "finalize: %s", B.err.c_str());
+    CFGPP_REQUIRE(skips.empty(), "finalize: internal error, %d skips left", (int)skips.size());
+    CFGPP_HIP_CHECK(hipDeviceSynchronize());
+    u->finalized = true;
+    return 0;
+}
+
+int cfgpp_unet_set_context(cfgpp_unet* u, const void* ehs, int rows, int tokens, const void* text_embeds,
+                           const void* time_ids, int cond_rows, void* stream) {
+    CFGPP_REQUIRE(u && u->finalized, "set_context: context not finalized");
+    CFGPP_REQUIRE(ehs && rows > 0 && rows <= u->cfg.max_rows, "set_context: rows=%d (max %d)", rows, u->cfg.max_rows);
+    CFGPP_REQUIRE(tokens == 77, "set_context: tokens=%d (the engine is built for 77 text tokens)", tokens);
+    if (u->cfg.addition_embed) {
+        CFGPP_REQUIRE(text_embeds && time_ids, "set_context: SDXL needs text_embeds and time_ids");
+        CFGPP_REQUIRE(cond_rows == rows || cond_rows == 1, "set_context: cond_rows=%d must be rows (%d) or 1", cond_rows, rows);
+    }
+    u->ctx_ehs = (const half_t*)ehs; u->ctx_rows = rows; u->ctx_tokens = tokens;
+    u->ctx_text = (const half_t*)text_embeds; u->ctx_tids = (const float*)time_ids; u->ctx_cond_rows = cond_rows;
+    for (auto& op : u->ctx_plan) { int e = op((hipStream_t)stream, rows); if (e) return e; }
+    u->ctx_set = true;
+    return 0;
+}
+
+int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t, void* eps_out, int rows,
+                       void* stream) {
+    CFGPP_REQUIRE(u && u->finalized, "forward: context not finalized");
+    CFGPP_REQUIRE(u->ctx_set, "forward: set_context has not been called");
+    CFGPP_REQUIRE(z && eps_out && z_rows > 0 && rows > 0 && rows <= u->cfg.max_rows, "forward: bad args (rows=%d max=%d)", rows, u->cfg.max_rows);
+    CFGPP_REQUIRE(rows == u->ctx_rows, "forward: rows=%d but context was set for %d rows", rows, u->ctx_rows);
+    u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
+    for (auto& op : u->plan) { int e = op((hipStream_t)stream, rows); if (e) return e; }
+    return 0;
+}
+
+double cfgpp_unet_flops(cfgpp_unet* u, int rows) {
+    if (!u || !u->finalized) return 0.0;
+    return 2.0 * (u->macs_per_row + u->attn_macs_per_row) * rows;
+}
+double cfgpp_unet_device_bytes(cfgpp_unet* u) { return u ? u->dev_bytes : 0.0; }
+
+// ---- single-op wrappers for tests ----------------------------------------------
+int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int amode, int H, int W,
+                   const void* w, int M, int N, const float* bias, const float* temb, int temb_ld,
+                   const void* resid, int rmode, int rld, void* out, int omode, int old_, int epi, void* stream) {
+    IGemmArgs a = base_args();
+    a.a0 = (const half_t*)a0; a.a1 = (const half_t*)a1; a.C0 = C0; a.C1 = C1; a.taps = taps; a.amode = amode; a.H = H; a.W = W;
+    a.w = (const half_t*)w; a.M = M; a.N = N; a.K = taps * (C0 + C1); a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
+    a.rows_per_batch = H * W; a.resid = (const half_t*)resid; a.rmode = rmode; a.rld = rld;
+    a.out = (half_t*)out; a.omode = omode; a.old = old_; a.epi = epi;
+    return igemm_launch(a, (hipStream_t)stream);
+}
+
+int cfgpp_op_igemm_heads(const void* a_, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
+                         void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
+                         int q_tok_pad, int tok_pad, void* stream) {
+    IGemmArgs a = base_args();
+    a.a0 = (const half_t*)a_; a.C0 = K; a.amode = 0; a.w = (const half_t*)w; a.M = M; a.N = N; a.K = K; a.bias = bias;
+    a.epi = EPI_HEADS; a.rows_per_batch = rows_per_batch; a.hq = (half_t*)hq; a.hk = (half_t*)hk; a.hvt = (half_t*)hvt;
+    a.part0 = part0; a.part_width = part_width; a.head_dim = head_dim; a.head_dim_pad = round_up(head_dim, 32);
+    a.heads = heads; a.q_tok_pad = q_tok_pad; a.tok_pad = tok_pad;
+    return igemm_launch(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

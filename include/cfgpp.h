@@ -1,0 +1,144 @@
+/* libcfgpp_hip.so - C ABI of the MI355X-native CFG++ sampling hot path.
+ *
+ * The reference (CFGpp-diffusion/CFGpp) has no FFI of its own: its hot path is
+ * the pure-Python seam
+ *     self.unet(z_in, t_in, encoder_hidden_states=..., added_cond_kwargs=...)['sample']
+ *         latent_diffusion.py:146,149,155      latent_sdxl.py:170,174,181
+ * plus the per-step elementwise sampler arithmetic
+ *         latent_diffusion.py:660-666 (and 179-180, 283-286, 479-490, 708-710, 855-866, 907-908)
+ *         latent_sdxl.py:738-744 (and 317-318, 453-456, 904-919, 972-973).
+ * This header declares what a binding for that seam calls instead.  Each entry
+ * point cites the reference lines it replaces.
+ *
+ * Conventions: plain C types only; every data pointer is a DEVICE pointer owned
+ * by the caller (PyTorch-ROCm tensor storage) unless the name says `host`; all
+ * work is enqueued asynchronously on the hipStream_t passed as `void* stream`
+ * and nothing synchronises; return 0 on success, < 0 on error with a message in
+ * cfgpp_last_error() (thread-local).  One context per device; not thread-safe.
+ */
+#ifndef CFGPP_H
+#define CFGPP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cfgpp_last_error(void);
+
+/* ---- fused sampler step (K12) ------------------------------------------- */
+
+/* Generalised DDIM update on n fp32 latent elements, in place:
+ *     eps_hat = eps_uc + lam*(eps_c - eps_uc)
+ *     z0t = (z - c1*A)/c2 ;  z = c3*z0t + c4*B ;  A,B in {eps_hat, eps_uc}
+ * replaces latent_diffusion.py:660-666 (CFG++: tweedie_uc=0, renoise_uc=1),
+ * :280-286 (CFG: 0,0), :177-180 (inversion CFG: 0,0 with coefficients swapped),
+ * :905-908 (inversion CFG++: 1,0) and latent_sdxl.py:738-744, 450-456, 315-318, 970-973.
+ * eps_is_half=1: eps are fp16 (the autocast UNet output) and every eps product is
+ * rounded to fp16 exactly as torch promotion does.  n must be a multiple of 4. */
+int cfgpp_step_ddim(void* z, void* z0t_out, const void* eps_uc, const void* eps_c, int eps_is_half,
+                    float lam, float c1, float c2, float c3, float c4,
+                    int tweedie_uc, int renoise_uc, long n, void* stream);
+
+/* k-diffusion UNet input scaling on fp16 latents: mode 0: xc = x / s
+ * (latent_diffusion.py:229-230, s = sqrt(sigma^2+1)); mode 1: xc = x * s (latent_sdxl.py:901). */
+int cfgpp_kdiff_input(const void* x, void* xc, float s, int mode, long n, void* stream);
+
+/* Euler / DPM-Solver++(2M) update on fp16 latents, in place.
+ * coef[9] = {lam, sigma, c_out_h, sigma_item, sigma_next, neg_exp_mh_h, expm1_mh_h, two_r, exp_mh_h}
+ * variant 0 = CFG (latent_diffusion.py:477-490, 329-333), 1 = CFG++ SD1.5 (:853-866, 706-710),
+ * 2 = CFG++ SDXL (latent_sdxl.py:901-919).  xl_form: denoised = x + c_out*eps instead of x - eps*sigma.
+ * euler_branch=1 selects x' = den + ((x - d_from)/sigma)*sigma_next.  den_out receives `denoised`. */
+int cfgpp_step_kdiff(void* x, void* den_out, void* old, const void* eps_uc, const void* eps_c,
+                     const float* coef_host, int variant, int xl_form, int euler_branch, int write_old,
+                     long n, void* stream);
+
+/* ---- UNet engine (replaces `self.unet(...)`) ------------------------------ */
+
+typedef struct cfgpp_unet_config {
+    int in_channels, out_channels;
+    int num_levels;               /* 4 for SD1.5, 3 for SDXL */
+    int block_out_channels[4];
+    int layers_per_block;         /* 2 */
+    int level_has_attn[4];        /* CrossAttn{Down,Up}Block2D per level (down order) */
+    int transformer_depth[4];     /* transformer layers per attention, per level */
+    int num_heads[4];             /* heads per level (SD1.5: 8 everywhere; SDXL: C/64) */
+    int cross_attention_dim;      /* 768 / 2048 */
+    int addition_embed;           /* 0 none, 1 = "text_time" (SDXL) */
+    int addition_time_embed_dim;  /* 256 */
+    int addition_pooled_dim;      /* 1280 */
+    int norm_groups;              /* 32 */
+    int sample_h, sample_w;       /* latent size this context is built for */
+    int max_rows;                 /* max UNet batch rows (2 * chains) */
+} cfgpp_unet_config;
+
+typedef struct cfgpp_unet cfgpp_unet;
+
+/* `pipe.unet` construction (latent_diffusion.py:63-67, latent_sdxl.py:40,50). */
+cfgpp_unet* cfgpp_unet_create(const cfgpp_unet_config* cfg, int device_id);
+void cfgpp_unet_destroy(cfgpp_unet* u);
+
+/* Load one state-dict entry by its diffusers key (e.g.
+ * "down_blocks.0.resnets.0.conv1.weight").  `host` points to HOST memory,
+ * dtype 0 = fp32, 1 = fp16; conv weights OIHW, linear weights [out,in].
+ * The library copies; returns -3 for an unknown key. */
+int cfgpp_unet_load_tensor(cfgpp_unet* u, const char* key, const void* host, int dtype,
+                           const long* shape, int ndim);
+/* Number of parameters still missing (0 = complete), names via cfgpp_last_error(). */
+int cfgpp_unet_missing(cfgpp_unet* u);
+/* Repack all weights into MFMA-friendly device layouts and build the launch plan. */
+int cfgpp_unet_finalize(cfgpp_unet* u);
+
+/* Conditioning for the next forwards: ehs [rows][77][cross_dim] fp16 (uc rows first,
+ * then c rows: the `torch.cat([uc, c])` of latent_diffusion.py:152); SDXL:
+ * text_embeds [cond_rows][1280] fp16, time_ids [cond_rows][6] fp32, cond_rows = rows or 1
+ * (1 = broadcast, the lambda==1.0 Lightning case of latent_sdxl.py:249-252).
+ * Precomputes the step-invariant cross-attention K/V of every block. */
+int cfgpp_unet_set_context(cfgpp_unet* u, const void* ehs, int rows, int tokens,
+                           const void* text_embeds, const void* time_ids, int cond_rows, void* stream);
+
+/* eps[rows][out_ch][H][W] (fp16) = UNet(z[(row % z_rows)], t).  z: [z_rows][in_ch][H][W],
+ * fp32 (z_is_half=0) or fp16.  rows = 2*z_rows reproduces cat([zt]*2) / chunk(2) of
+ * latent_diffusion.py:153-156: eps_uc = eps[0:z_rows], eps_c = eps[z_rows:]. */
+int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t,
+                       void* eps_out, int rows, void* stream);
+
+/* Algorithmic FLOPs (2*MAC over conv/linear/attention matmuls) of one forward at `rows`. */
+double cfgpp_unet_flops(cfgpp_unet* u, int rows);
+/* Bytes of device memory held (weights + activations). */
+double cfgpp_unet_device_bytes(cfgpp_unet* u);
+
+/* ---- single ops, exposed for parity tests and micro-benchmarks ------------- */
+int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
+                       float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
+                       int dst_padded, void* stream);
+int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
+                       float eps, void* stream);
+int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
+                       int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
+int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
+                     int R, int zB, int Cin, int H, int W, int Cout, void* stream);
+int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
+                      int R, int H, int W, int C, int Cout, void* stream);
+int cfgpp_op_sinusoid(const float* vals, float scalar, float* out, int count, int dim, int out_ld, int out_off,
+                      void* stream);
+int cfgpp_op_skinny_gemm(const float* x, int ldx, const void* w, const float* bias, const float* addend, int add_ld,
+                         float* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream);
+int cfgpp_op_f16_to_f32_rows(const void* in, float* out, int rows, int cols, int out_ld, int out_off, void* stream);
+
+/* Generic implicit GEMM (conv3x3 / conv1x1 / linear), see cfgpp_amd/csrc/igemm.h.
+ * a0/a1: activation sources (C0/C1 channels), amode 0 linear rows, 1 halo-padded NHWC,
+ * 2 padded stride-2, 3 padded nearest-2x upsample; w [N][taps*(C0+C1)] fp16 (k = tap*Cin + c);
+ * epi 0 store (+bias +temb +resid), 1 GEGLU (packed weights).  omode/rmode: 0 linear, 1 padded. */
+int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int amode, int H, int W,
+                   const void* w, int M, int N, const float* bias, const float* temb, int temb_ld,
+                   const void* resid, int rmode, int rld, void* out, int omode, int old_, int epi,
+                   void* stream);
+/* QKV / KV projection with head-major scatter (EPI_HEADS) */
+int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
+                         void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
+                         int q_tok_pad, int tok_pad, void* stream);
+void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFGPP_H */

@@ -1,0 +1,404 @@
+#!/usr/bin/env python
+"""One-shot GPU diagnostic: every kernel against its fp32 torch reference, error
+statistics + micro-benchmarks written to gpurun_out/diag.json.  Never raises:
+each case is isolated so one broken kernel does not hide the others.
+
+    python tests/gpu_diag.py [--quick] [--full-unet]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import hip_ops as H  # noqa: E402
+from cfgpp_amd import _lib  # noqa: E402
+
+RESULTS = {}
+
+
+def case(name):
+    def deco(fn):
+        def run(*a, **k):
+            t0 = time.time()
+            try:
+                r = fn(*a, **k)
+                torch.cuda.synchronize()
+                RESULTS[name] = r
+                print(f"[diag] {name}: {json.dumps(r)}  ({time.time() - t0:.1f}s)", flush=True)
+            except Exception as e:  # noqa: BLE001
+                RESULTS[name] = {"error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]}
+                print(f"[diag] {name}: ERROR {type(e).__name__}: {e}", flush=True)
+        return run
+    return deco
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().float()
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+# ----------------------------------------------------------------------------
+@case("gemm_basic")
+def t_gemm(cfgs=(0, 1, 2, 3), M=300, N=192, K=128):
+    out = {}
+    a = rnd(M, K, seed=1)
+    w = rnd(N, K, scale=K ** -0.5, seed=2)
+    b = rnd(N, scale=0.1, seed=3)
+    r = rnd(M, N, seed=4)
+    ref = a @ w.t() + b + r
+    for c in cfgs:
+        H.lib().cfgpp_igemm_force_config(c)
+        got = H.linear(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), b.to(H.DEV), r.to(H.DEV, torch.float16))
+        out[f"cfg{c}"] = H.err_stats(got, ref)
+    H.lib().cfgpp_igemm_force_config(0)
+    return out
+
+
+@case("gemm_transpose_check")
+def t_gemm_t():
+    # A = I-like asymmetric check: out[m][n] = W[n][m] when A = identity (K = M)
+    M = K = 128
+    N = 64
+    a = torch.eye(M)
+    w = (torch.arange(N * K).reshape(N, K) % 251).float() / 64.0
+    got = H.linear(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16))
+    return H.err_stats(got, w.t().half().float())
+
+
+@case("gemm_geglu")
+def t_geglu(M=260, C=64):
+    a = rnd(M, C, seed=5)
+    w = rnd(8 * C, C, scale=C ** -0.5, seed=6)
+    b = rnd(8 * C, scale=0.1, seed=7)
+    h = a @ w.t() + b
+    v, g = h.chunk(2, dim=-1)
+    ref = v * F.gelu(g)
+    wp, bp = H.pack_geglu(w, b)
+    out = {}
+    for c in (1, 2):
+        H.lib().cfgpp_igemm_force_config(c)
+        got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
+        out[f"cfg{c}"] = H.err_stats(got, ref)
+    H.lib().cfgpp_igemm_force_config(0)
+    return out
+
+
+@case("conv3x3")
+def t_conv(N=2, Cin=64, Cout=128, Hh=12, Ww=10):
+    x = rnd(N, Cin, Hh, Ww, seed=8)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=9)
+    b = rnd(Cout, scale=0.1, seed=10)
+    temb = rnd(N, Cout, scale=0.5, seed=11)
+    res = rnd(N, Cout, Hh, Ww, seed=12)
+    ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
+    out = {}
+    for c in (1, 2, 3):
+        H.lib().cfgpp_igemm_force_config(c)
+        got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), Hh, Ww, 1, temb.to(H.DEV), Cout, H.to_pn(res))
+        out[f"cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
+    H.lib().cfgpp_igemm_force_config(0)
+    return out
+
+
+@case("conv3x3_stride2")
+def t_conv_s2(N=2, C=64, Hh=12, Ww=8):
+    x = rnd(N, C, Hh, Ww, seed=13)
+    w = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=14)
+    b = rnd(C, scale=0.1, seed=15)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), Hh // 2, Ww // 2, 2)
+    return H.err_stats(H.from_pn(got), ref)
+
+
+@case("conv3x3_upsample")
+def t_conv_up(N=2, C=64, Hh=6, Ww=5):
+    x = rnd(N, C, Hh, Ww, seed=16)
+    w = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=17)
+    b = rnd(C, scale=0.1, seed=18)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 2 * Hh, 2 * Ww, 3)
+    return H.err_stats(H.from_pn(got), ref)
+
+
+@case("conv1x1_two_sources")
+def t_conv1(N=2, C0=128, C1=64, Cout=64, Hh=9, Ww=7):
+    x0, x1 = rnd(N, C0, Hh, Ww, seed=19), rnd(N, C1, Hh, Ww, seed=20)
+    w = rnd(Cout, C0 + C1, scale=(C0 + C1) ** -0.5, seed=21)
+    b = rnd(Cout, scale=0.1, seed=22)
+    ref = F.conv2d(torch.cat([x0, x1], 1), w[:, :, None, None], b)
+    got = H.conv1x1_2src(H.to_pn(x0), H.to_pn(x1), w.to(H.DEV, torch.float16), b.to(H.DEV))
+    return H.err_stats(H.from_pn(got), ref)
+
+
+@case("groupnorm")
+def t_gn():
+    out = {}
+    for (N, C0, C1, Hh, Ww, silu) in ((2, 64, 0, 8, 8, 1), (2, 128, 64, 7, 5, 1), (1, 320, 0, 16, 16, 0), (2, 1280, 640, 8, 8, 1),
+                                      (1, 2560, 0, 4, 4, 1)):
+        x0 = rnd(N, C0, Hh, Ww, seed=23) * 2 + 0.5
+        x1 = rnd(N, C1, Hh, Ww, seed=24) if C1 else None
+        C = C0 + C1
+        g, b = 1 + rnd(C, scale=0.1, seed=25), rnd(C, scale=0.1, seed=26)
+        xin = torch.cat([x0, x1], 1) if C1 else x0
+        ref = F.group_norm(xin, 32, g, b, 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        got = H.groupnorm(H.to_pn(x0), H.to_pn(x1) if C1 else None, g.to(H.DEV), b.to(H.DEV), 32, 1e-5, silu)
+        out[f"{N}x{C0}+{C1}x{Hh}x{Ww}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
+    # token-major destination
+    x0 = rnd(2, 64, 6, 6, seed=27)
+    g, b = 1 + rnd(64, scale=0.1, seed=28), rnd(64, scale=0.1, seed=29)
+    ref = F.group_norm(x0, 32, g, b, 1e-6).permute(0, 2, 3, 1).reshape(-1, 64)
+    got = H.groupnorm(H.to_pn(x0), None, g.to(H.DEV), b.to(H.DEV), 32, 1e-6, 0, dst_padded=False)
+    out["tokens"] = H.err_stats(got, ref)
+    return out
+
+
+@case("layernorm")
+def t_ln():
+    out = {}
+    for C in (64, 320, 640, 1280):
+        x = rnd(37, C, seed=30) * 3 + 1
+        g, b = 1 + rnd(C, scale=0.1, seed=31), rnd(C, scale=0.1, seed=32)
+        ref = F.layer_norm(x, (C,), g, b, 1e-5)
+        got = H.layernorm(x.to(H.DEV, torch.float16), g.to(H.DEV), b.to(H.DEV))
+        out[str(C)] = H.err_stats(got, ref)
+    return out
+
+
+@case("attention")
+def t_attn():
+    out = {}
+    for (B, h, Nq, Nk, d) in ((1, 2, 64, 64, 32), (2, 2, 256, 256, 64), (1, 8, 192, 192, 40), (1, 4, 128, 128, 80), (1, 2, 64, 64, 160),
+                              (2, 2, 100, 77, 64), (1, 8, 256, 77, 40), (1, 2, 1024, 1024, 64)):
+        q, k, v = rnd(B, h, Nq, d, seed=33), rnd(B, h, Nk, d, seed=34), rnd(B, h, Nk, d, seed=35)
+        ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, Nq, h * d)
+        hq, hk, hvt, qp, kp = H.make_heads(q, k, v)
+        got = H.attention(hq, hk, hvt, B, h, d, Nq, Nk, qp, kp)
+        out[f"B{B}h{h}q{Nq}k{Nk}d{d}"] = H.err_stats(got, ref)
+    return out
+
+
+@case("heads_projection")
+def t_heads(B=2, tokens=96, C=128, nheads=4):
+    a = rnd(B * tokens, C, seed=36)
+    w = rnd(3 * C, C, scale=C ** -0.5, seed=37)
+    d = C // nheads
+    qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
+    hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
+    y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
+    out = {}
+    out["q"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+    out["k"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
+    out["vt"] = H.err_stats(hvt[:, :d, :tokens].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+    out["pad_zero"] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :, tokens:].abs().sum() == 0)
+    return out
+
+
+@case("conv_in_out")
+def t_cio():
+    out = {}
+    z = rnd(2, 4, 16, 12, seed=38)
+    w = rnd(64, 4, 3, 3, scale=1 / 6, seed=39)
+    b = rnd(64, scale=0.1, seed=40)
+    ref = F.conv2d(torch.cat([z, z]), w, b, padding=1)
+    got = H.conv_in(z.to(H.DEV), w, b.to(H.DEV), 4)
+    out["conv_in_f32"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
+    got = H.conv_in(z.to(H.DEV, torch.float16), w, b.to(H.DEV), 4)
+    out["conv_in_f16"] = H.err_stats(H.from_pn(got), ref)
+    x = rnd(3, 64, 10, 8, seed=41)
+    w2 = rnd(4, 64, 3, 3, scale=(9 * 64) ** -0.5, seed=42)
+    b2 = rnd(4, scale=0.1, seed=43)
+    ref2 = F.conv2d(x, w2, b2, padding=1)
+    out["conv_out"] = H.err_stats(H.conv_out(H.to_pn(x), w2, b2.to(H.DEV)), ref2)
+    return out
+
+
+@case("sinusoid_skinny")
+def t_small():
+    from oracle.unet_ref import timestep_embedding
+    out = {}
+    vals = torch.tensor([981.0, 1.0, 500.0, 1024.0, 0.0])
+    out["sinusoid"] = H.err_stats(H.sinusoid(vals.to(H.DEV), 320), timestep_embedding(vals, 320))
+    x = rnd(5, 320, seed=44)
+    w = rnd(1280, 320, scale=320 ** -0.5, seed=45)
+    b = rnd(1280, scale=0.1, seed=46)
+    ref = F.silu(F.linear(F.silu(x), w, b))
+    out["skinny_m5"] = H.err_stats(H.skinny(x.to(H.DEV), w.to(H.DEV, torch.float16), b.to(H.DEV), True, True), ref)
+    out["skinny_m1"] = H.err_stats(H.skinny(x[:1].contiguous().to(H.DEV), w.to(H.DEV, torch.float16), b.to(H.DEV), True, True), ref[:1])
+    return out
+
+
+@case("step_kernels_golden")
+def t_step():
+    import numpy as np
+    from cfgpp_amd import engine as E
+    from cfgpp_amd.coeffs import ddim_coeffs
+    from cfgpp_amd.schedule import SchedulerTables
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sampler_golden.npz"))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    tag, tb, lam = "G2/sd_ddim_cfgpp_h", SchedulerTables(50), 0.6
+    z, e, z0, zt = T(g[tag + "/unet_z"]), T(g[tag + "/unet_eps"]), T(g[tag + "/z0t"]), T(g[tag + "/zt"])
+    bad = 0
+    for i, t in enumerate(tb.timesteps):
+        zi = z[i][0:1].contiguous().to(H.DEV)
+        z0o = torch.empty_like(zi)
+        co = ddim_coeffs(tb.alpha(t), tb.alpha(int(t) - tb.skip), eps_half=True)
+        E.step_ddim(zi, z0o, e[i][0:1].contiguous().to(H.DEV), e[i][1:2].contiguous().to(H.DEV), lam, co, False, True)
+        bad += int((z0o.cpu() != z0[i]).sum()) + int((zi.cpu() != zt[i]).sum())
+    return {"mismatching_elements": bad, "steps": int(len(tb.timesteps))}
+
+
+def unet_case(cfg_name, R, hw, seed=0, iters=0):
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import CONFIGS
+    from cfgpp_amd.weights import synth_state_dict
+    from oracle.unet_ref import UNetRef
+    cfg = CONFIGS[cfg_name]
+    sd = synth_state_dict(cfg, seed)
+    zB = R // 2
+    z = rnd(zB, 4, hw, hw, seed=50)
+    ehs = rnd(R, 77, cfg.cross_attention_dim, scale=0.5, seed=51)
+    te = ti = None
+    ack = None
+    if cfg.addition_embed:
+        te = rnd(R, cfg.addition_pooled_dim, scale=0.5, seed=52)
+        ti = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * R)
+        ack = {"text_embeds": te, "time_ids": ti}
+    t0 = time.time()
+    net = HipUNet(cfg, max_rows=R, sample_hw=(hw, hw))
+    net.load_state_dict(sd).finalize()
+    t_build = time.time() - t0
+    net.set_context(ehs, te, ti)
+    out = {}
+    for tval in (981.0, 1.0):
+        eps = net.forward(z.to(H.DEV), tval)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        ref = UNetRef(cfg, sd)(torch.cat([z, z]), tval, ehs, ack)["sample"]
+        out[f"t{int(tval)}"] = dict(H.err_stats(eps, ref), cpu_ref_s=round(time.time() - t0, 2))
+    out["build_s"] = round(t_build, 1)
+    out["device_GB"] = round(net.device_bytes() / 1e9, 2)
+    if iters:
+        zd = z.to(H.DEV)
+        dt = timeit(lambda: net.forward(zd, 500.0), iters=iters, warm=2)
+        out["fwd_ms"] = round(dt * 1e3, 3)
+        out["TFLOPs"] = round(net.flops(R) / dt / 1e12, 1)
+    return out
+
+
+@case("unet_tiny_sd")
+def t_unet_tiny_sd():
+    return unet_case("tiny_sd", 4, 16, iters=5)
+
+
+@case("unet_tiny_xl")
+def t_unet_tiny_xl():
+    return unet_case("tiny_xl", 2, 16, iters=5)
+
+
+@case("unet_sd15_r2")
+def t_unet_sd15():
+    return unet_case("sd15", 2, 64, iters=5)
+
+
+@case("unet_sdxl_r2_64")
+def t_unet_sdxl():
+    return unet_case("sdxl", 2, 64, iters=3)
+
+
+@case("microbench")
+def t_bench():
+    out = {}
+    # GEMMs at SD1.5 / SDXL shapes, batch 16 rows
+    for (name, M, N, K) in (("geglu_l0", 65536, 2560, 320), ("qkv_l0", 65536, 960, 320), ("ffout_l0", 65536, 320, 1280),
+                            ("geglu_l1", 16384, 5120, 640), ("xl_geglu", 4096, 10240, 1280), ("xl_ffout", 4096, 1280, 5120),
+                            ("xl_qkv", 4096, 3840, 1280)):
+        a = torch.randn(M, K, device=H.DEV, dtype=torch.float16)
+        w = torch.randn(N, K, device=H.DEV, dtype=torch.float16) * K ** -0.5
+        outb = torch.empty(M, N, device=H.DEV, dtype=torch.float16)
+        fn = lambda: H.igemm(a, None, K, 0, 1, 0, 0, 0, w, M, N, out=outb, omode=0, old=N)  # noqa: E731
+        dt = timeit(fn, iters=10)
+        out[name] = dict(ms=round(dt * 1e3, 3), TF=round(2.0 * M * N * K / dt / 1e12, 1))
+    for (name, N, C, Co, hw) in (("conv_l0", 16, 320, 320, 64), ("conv_l1", 16, 640, 640, 32), ("conv_l2", 16, 1280, 1280, 16),
+                                 ("conv_l3", 16, 1280, 1280, 8), ("conv_up0", 16, 2560, 1280, 16), ("xl_conv_128", 4, 320, 320, 128)):
+        x = torch.randn(N, hw + 2, hw + 2, C, device=H.DEV, dtype=torch.float16)
+        w = torch.randn(Co, 9 * C, device=H.DEV, dtype=torch.float16) * (9 * C) ** -0.5
+        o = H.empty_pn(N, hw, hw, Co)
+        fn = lambda: H.igemm(x, None, C, 0, 9, 1, hw, hw, w, N * hw * hw, Co, out=o, omode=1, old=Co)  # noqa: E731
+        dt = timeit(fn, iters=10)
+        out[name] = dict(ms=round(dt * 1e3, 3), TF=round(2.0 * N * hw * hw * Co * 9 * C / dt / 1e12, 1))
+    for (name, B, h, Nn, d) in (("attn_l0_d40", 16, 8, 4096, 40), ("attn_l1_d80", 16, 8, 1024, 80), ("attn_xl_d64", 4, 20, 1024, 64),
+                                ("attn_xl_4096", 4, 10, 4096, 64)):
+        dp = H.round_up(d, 32)
+        hq = torch.randn(B * h, Nn, dp, device=H.DEV, dtype=torch.float16)
+        hk = torch.randn(B * h, Nn, dp, device=H.DEV, dtype=torch.float16)
+        hvt = torch.randn(B * h, dp, Nn, device=H.DEV, dtype=torch.float16)
+        o = torch.empty(B, Nn, h * d, device=H.DEV, dtype=torch.float16)
+        fn = lambda: _lib.check(H.lib().cfgpp_op_attention(H.P(hq), H.P(hk), H.P(hvt), H.P(o), B, h, d, Nn, Nn, Nn, Nn, H.stream()), "attn")  # noqa: E731
+        dt = timeit(fn, iters=10)
+        out[name] = dict(ms=round(dt * 1e3, 3), TF=round(4.0 * B * h * Nn * Nn * d / dt / 1e12, 1))
+    # GroupNorm / LayerNorm bandwidth
+    for (name, N, C, hw) in (("gn_320_64", 16, 320, 64), ("gn_1280_16", 16, 1280, 16), ("gn_xl_320_128", 4, 320, 128)):
+        x = torch.randn(N, hw + 2, hw + 2, C, device=H.DEV, dtype=torch.float16)
+        g = torch.ones(C, device=H.DEV)
+        b = torch.zeros(C, device=H.DEV)
+        fn = lambda: H.groupnorm(x, None, g, b, 32, 1e-5, 1)  # noqa: E731
+        dt = timeit(fn, iters=10)
+        out[name] = dict(ms=round(dt * 1e3, 3), GBs=round(3 * 2.0 * N * hw * hw * C / dt / 1e9, 1))
+    for (name, rows, C) in (("ln_320", 65536, 320), ("ln_1280", 16384, 1280)):
+        x = torch.randn(rows, C, device=H.DEV, dtype=torch.float16)
+        g = torch.ones(C, device=H.DEV)
+        b = torch.zeros(C, device=H.DEV)
+        fn = lambda: H.layernorm(x, g, b)  # noqa: E731
+        dt = timeit(fn, iters=10)
+        out[name] = dict(ms=round(dt * 1e3, 3), GBs=round(2 * 2.0 * rows * C / dt / 1e9, 1))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--full-unet", action="store_true")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "diag.json"))
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    print("[diag] device:", torch.cuda.get_device_name(0), flush=True)
+    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_gn(); t_ln(); t_attn(); t_heads()
+    t_cio(); t_small(); t_step()
+    t_unet_tiny_sd(); t_unet_tiny_xl()
+    if not args.quick:
+        t_bench()
+    if args.full_unet:
+        t_unet_sd15(); t_unet_sdxl()
+    with open(args.out, "w") as f:
+        json.dump(RESULTS, f, indent=1)
+    print("[diag] wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()
