@@ -41,6 +41,13 @@ def ddim_coeffs(a_tweedie, a_renoise, eps_half: bool = True, semantics: str = "c
     return (_first(c1, eps_half, semantics), float(c2), float(c3), _first(c4, eps_half, semantics))
 
 
+def ddim_coeffs_pinned(sqrt4, eps_half: bool = True, semantics: str = "cpu"):
+    """Same as :func:`ddim_coeffs` but from the pinned sqrt tables
+    (``SchedulerTables.ddim_sqrt_coeffs``) - bit-stable across hosts."""
+    c1, c2, c3, c4 = (_s(v) for v in sqrt4)
+    return (_first(c1, eps_half, semantics), float(c2), float(c3), _first(c4, eps_half, semantics))
+
+
 def kdiff_input_scale_sd(sigma) -> float:
     """divisor of ``x / (sigma**2 + 1)**0.5`` (latent_diffusion.py:229-230)."""
     return float((_s(sigma) ** 2 + 1) ** 0.5)

@@ -1,0 +1,73 @@
+"""The engine object a Solver drives: UNet forward + fused step kernels on ONE GPU.
+
+``HipEngine`` is the only engine the product path constructs.  Tests may inject
+another object with the same methods (``tests/mock_engine.py`` runs the solver
+control flow on CPU against the oracle); nothing in this package falls back to
+it.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import engine as E
+from ._lib import CfgppError
+from .unet_config import CONFIGS, UNetConfig
+from .weights import load_safetensors_iter, synth_state_dict_iter
+
+
+class HipEngine:
+    def __init__(self, cfg: UNetConfig, max_batch: int = 1, latent_hw: Optional[Tuple[int, int]] = None,
+                 device=None, weights="synthetic", weight_seed: int = 0):
+        if isinstance(cfg, str):
+            cfg = CONFIGS[cfg]
+        if not torch.cuda.is_available():
+            raise CfgppError("HipEngine needs a ROCm GPU; the HIP path has no CPU fallback")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise CfgppError(f"HipEngine cannot run on device '{dev}': the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.cfg = cfg
+        self.max_batch = int(max_batch)
+        self.unet = E.HipUNet(cfg, max_rows=2 * self.max_batch, sample_hw=latent_hw, device=self.device.index)
+        if weights == "synthetic":
+            items = synth_state_dict_iter(cfg, weight_seed)
+        elif isinstance(weights, str):
+            items = load_safetensors_iter(weights)
+        else:
+            items = weights.items() if isinstance(weights, dict) else weights
+        self.unet.load_state_dict(items).finalize()
+        self.H, self.W = self.unet.H, self.unet.W
+        self._ctx_key = None
+        self._eps = None
+
+    # -- conditioning ------------------------------------------------------------
+    def set_context(self, uc: torch.Tensor, c: torch.Tensor, text_embeds=None, time_ids=None):
+        """uc, c: [B or 1, 77, D].  Rows are laid out [uc_1..uc_B, c_1..c_B]
+        (the batched form of torch.cat([uc, c]), latent_diffusion.py:152)."""
+        B = max(int(uc.shape[0]), int(c.shape[0]))
+        if B > self.max_batch:
+            raise CfgppError(f"batch {B} exceeds engine max_batch {self.max_batch}")
+        if uc.shape[0] != B:
+            uc = uc.expand(B, -1, -1)
+        if c.shape[0] != B:
+            c = c.expand(B, -1, -1)
+        ehs = torch.cat([uc, c], dim=0)
+        self.unet.set_context(ehs, text_embeds, time_ids)
+        self.B = B
+        self._eps = torch.empty((2 * B, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=self.device)
+
+    def predict(self, z: torch.Tensor, t: float):
+        """(eps_uc, eps_c), each [B,4,H,W] fp16 - replaces predict_noise's UNet call + chunk(2)."""
+        eps = self.unet.forward(z, float(t), self._eps)
+        return eps[: self.B], eps[self.B:]
+
+    # -- fused sampler arithmetic ---------------------------------------------------
+    step_ddim = staticmethod(E.step_ddim)
+    kdiff_input = staticmethod(E.kdiff_input)
+    step_kdiff = staticmethod(E.step_kdiff)
+
+    def flops_per_forward(self, rows: int) -> float:
+        return self.unet.flops(rows)

@@ -25,6 +25,8 @@ configs (diffusers 0.27.1, pinned by the reference's environment.yaml:87).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -33,11 +35,37 @@ BETA_START = 0.00085
 BETA_END = 0.012
 
 
-def alphas_cumprod() -> torch.Tensor:
-    """abar[0..999], fp32, exactly as diffusers' ``scaled_linear`` schedule."""
+def alphas_cumprod_computed() -> torch.Tensor:
+    """abar[0..999], fp32, by diffusers' ``scaled_linear`` formula.  NOT bit-stable
+    across hosts: ``torch.linspace`` differs by 1 ulp between CPU ISAs (observed
+    between the build container and the MI355X box), which flips fp32 sampler
+    outputs.  Use :func:`alphas_cumprod`."""
     betas = torch.linspace(BETA_START ** 0.5, BETA_END ** 0.5, NUM_TRAIN_TIMESTEPS,
                            dtype=torch.float32) ** 2
     return torch.cumprod(1.0 - betas, dim=0)
+
+
+_ALPHA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "alphas_cumprod_f32.npy")
+
+
+def alphas_cumprod() -> torch.Tensor:
+    """abar[0..999], fp32: the pinned table (``data/alphas_cumprod_f32.npy``) = the
+    values the reference's scheduler produced when the golden vectors were
+    recorded (tests/golden G1/total_alphas), identical on every host."""
+    return torch.from_numpy(np.load(_ALPHA_FILE).astype(np.float32)).clone()
+
+
+_SQRT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ddim_sqrt_tables.npz")
+
+
+def ddim_sqrt_tables():
+    """(sqrt(a), sqrt(1-a)) over the SHIFTED table ``cat([1.0], abar)`` (1001 entries), fp32.
+    Pinned data, because ``torch.sqrt`` on fp32 is not bit-stable across hosts either
+    (Sleef AVX2 vs AVX-512 kernels differ by 1 ulp on a few entries - observed between
+    the build container and the MI355X box).  The file holds what the reference's
+    ``at.sqrt()`` / ``(1-at).sqrt()`` evaluated to when the golden vectors were recorded."""
+    d = np.load(_SQRT_FILE)
+    return torch.from_numpy(d["sqrt_a"].astype(np.float32)).clone(), torch.from_numpy(d["sqrt_1ma"].astype(np.float32)).clone()
 
 
 def ddim_timesteps(num_sampling: int, steps_offset: int = 1) -> torch.Tensor:
@@ -98,6 +126,7 @@ class SchedulerTables:
             self.final_alpha_cumprod = None                        # latent_sdxl.py:417
         # the shifted table (quirk Q1)
         self.alphas_cumprod = torch.cat([torch.tensor([1.0]), self.total_alphas])
+        self._sqrt_a, self._sqrt_1ma = ddim_sqrt_tables()
 
     # -- reference index rules -------------------------------------------------
     def alpha(self, t) -> torch.Tensor:
@@ -112,6 +141,26 @@ class SchedulerTables:
     def alpha_wrap(self, t) -> torch.Tensor:
         """Unguarded index used by the SDXL DDIM loops (latent_sdxl.py:732-734)."""
         return self.alphas_cumprod[int(t)]
+
+    def _index(self, t, wrap: bool) -> int:
+        """index into the shifted table for ``alpha(t)`` (guarded) or ``alphas_cumprod[t]`` (wrap)."""
+        t = int(t)
+        if wrap:
+            return t % len(self.alphas_cumprod)          # python negative indexing
+        if t >= 0:
+            return t
+        if self.final_alpha_cumprod is None:
+            raise AttributeError("final_alpha_cumprod")
+        return 1                                         # final_alpha_cumprod = abar[0] = shifted[1]
+
+    def ddim_sqrt_coeffs(self, t, wrap: bool = False, inversion: bool = False):
+        """(c1, c2, c3, c4) = sqrt(1-a_tw), sqrt(a_tw), sqrt(a_rn), sqrt(1-a_rn) as python floats
+        (exact fp32 values) for the step at timestep ``t``:
+        forward   a_tw = alpha(t),        a_rn = alpha(t - skip)   (latent_diffusion.py:655-666)
+        inversion a_tw = alpha(t - skip), a_rn = alpha(t)          (latent_diffusion.py:901-908)"""
+        i_t, i_p = self._index(t, wrap), self._index(int(t) - self.skip, wrap)
+        i_tw, i_rn = (i_p, i_t) if inversion else (i_t, i_p)
+        return (float(self._sqrt_1ma[i_tw]), float(self._sqrt_a[i_tw]), float(self._sqrt_a[i_rn]), float(self._sqrt_1ma[i_rn]))
 
     # -- k-diffusion helpers ---------------------------------------------------
     def timestep(self, sigma: torch.Tensor) -> torch.Tensor:

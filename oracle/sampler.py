@@ -91,7 +91,7 @@ def ddim_coeffs(a_tweedie, a_renoise):
     return (1 - a_tw).sqrt(), a_tw.sqrt(), a_rn.sqrt(), (1 - a_rn).sqrt()
 
 
-def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, renoise_uc: bool):
+def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, renoise_uc: bool, sqrt4=None):
     """One generalised DDIM update.
 
         z0t = (z - sqrt(1-a_tw) * A) / sqrt(a_tw)
@@ -103,8 +103,13 @@ def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, ren
     inversion CFG++: a_tw=alpha(t-skip), a_rn=alpha(t),      A=eps_uc,  B=eps_hat
 
     z is fp32; z0t and z' are fp32 (fp16 eps products are rounded to fp16 first).
+    ``sqrt4`` = (c1, c2, c3, c4) overrides the torch ``sqrt`` evaluation with pinned values
+    (``torch.sqrt`` differs by 1 ulp between hosts; see cfgpp_amd/schedule.py).
     """
-    c1, c2, c3, c4 = ddim_coeffs(a_tweedie, a_renoise)
+    if sqrt4 is not None:
+        c1, c2, c3, c4 = (_s(v) for v in sqrt4)
+    else:
+        c1, c2, c3, c4 = ddim_coeffs(a_tweedie, a_renoise)
     eps_hat = cfg_mix(eps_uc, eps_c, lam)
     A = eps_uc if tweedie_uc else eps_hat
     B = eps_uc if renoise_uc else eps_hat
@@ -240,7 +245,8 @@ def sample_ddim(unet_fn, zT, tables, lam, cfgpp=True, wrap_index=False, callback
         else:
             at, at_prev = tables.alpha(t), tables.alpha(int(t) - tables.skip)
         eps_uc, eps_c = unet_fn(zt, t)
-        z0t, zt = ddim_step(zt, eps_uc, eps_c, lam, at, at_prev, tweedie_uc=False, renoise_uc=cfgpp)
+        z0t, zt = ddim_step(zt, eps_uc, eps_c, lam, at, at_prev, tweedie_uc=False, renoise_uc=cfgpp,
+                            sqrt4=tables.ddim_sqrt_coeffs(t, wrap=wrap_index))
         if callback_fn is not None:
             kw = callback_fn(step, t, {"z0t": z0t, "zt": zt, "decode": None})
             z0t, zt = kw["z0t"], kw["zt"]
@@ -253,5 +259,6 @@ def invert_ddim(unet_fn, z0, tables, lam, cfgpp=True):
     for t in reversed(tables.timesteps):
         at, at_prev = tables.alpha(t), tables.alpha(int(t) - tables.skip)
         eps_uc, eps_c = unet_fn(zt, t)
-        _, zt = ddim_step(zt, eps_uc, eps_c, lam, at_prev, at, tweedie_uc=cfgpp, renoise_uc=False)
+        _, zt = ddim_step(zt, eps_uc, eps_c, lam, at_prev, at, tweedie_uc=cfgpp, renoise_uc=False,
+                          sqrt4=tables.ddim_sqrt_coeffs(t, inversion=True))
     return zt

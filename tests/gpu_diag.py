@@ -257,7 +257,7 @@ def t_small():
 def t_step():
     import numpy as np
     from cfgpp_amd import engine as E
-    from cfgpp_amd.coeffs import ddim_coeffs
+    from cfgpp_amd.coeffs import ddim_coeffs_pinned
     from cfgpp_amd.schedule import SchedulerTables
     g = np.load(os.path.join(ROOT, "tests", "golden", "sampler_golden.npz"))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
@@ -267,7 +267,7 @@ def t_step():
     for i, t in enumerate(tb.timesteps):
         zi = z[i][0:1].contiguous().to(H.DEV)
         z0o = torch.empty_like(zi)
-        co = ddim_coeffs(tb.alpha(t), tb.alpha(int(t) - tb.skip), eps_half=True)
+        co = ddim_coeffs_pinned(tb.ddim_sqrt_coeffs(t), eps_half=True)
         E.step_ddim(zi, z0o, e[i][0:1].contiguous().to(H.DEV), e[i][1:2].contiguous().to(H.DEV), lam, co, False, True)
         bad += int((z0o.cpu() != z0[i]).sum()) + int((zi.cpu() != zt[i]).sum())
     return {"mismatching_elements": bad, "steps": int(len(tb.timesteps))}
