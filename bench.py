@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Benchmark of the CFG++ sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config sd15|sdxl|sdxl_lightning|sdxl_edit]
+
+One "step" = one pass of the hot path over one batch of synthetic prompts: B
+independent 50-NFE DDIM-CFG++ chains (UNet at batch 2B + fused step kernel per
+NFE) followed by the VAE decode and the device->host copy of the images, i.e.
+exactly what ``solver.sample()`` returns in the reference
+(latent_diffusion.py:634-679).  Default workload = BASELINE.json configs[1]:
+SD1.5 512x512, ddim_cfg++, 50 NFE, lambda = 0.6, batch 8 on one MI355X.  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the
+same per-GPU batch (weak scaling) on its own prompt shard; rank 0 broadcasts the
+conditioning once over RCCL; nothing is exchanged inside the loop.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_FP16 = 2.5e15      # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+VAE_DEC_FLOPS = {512: 2.51e12, 1024: 10.47e12}
+VAE_ENC_FLOPS = {512: 1.12e12, 1024: 4.88e12}
+
+WORKLOADS = {
+    # name: (module, solver, cfg name, NFE, lambda, per-GPU batch, image size, description)
+    "sd15": ("sd", "ddim_cfg++", "sd15", 50, 0.6, 8, 512, "SD1.5 512x512 ddim_cfg++ 50 NFE lambda=0.6 batch=8/GPU"),
+    "sdxl": ("xl", "ddim_cfg++", "sdxl", 50, 0.6, 2, 1024, "SDXL 1024x1024 ddim_cfg++ 50 NFE lambda=0.6 batch=2/GPU"),
+    "sdxl_lightning": ("xl", "ddim_cfg++_lightning", "sdxl", 4, 1.0, 8, 1024,
+                       "SDXL-Lightning arch 1024x1024 ddim_cfg++_lightning 4 NFE lambda=1.0 batch=8/GPU"),
+    "sdxl_edit": ("xl", "ddim_inversion_cfg++", "sdxl", 50, 0.6, 1, 1024,
+                  "SDXL 1024x1024 ddim_edit_cfg++ (tgt=src) 50+50 NFE lambda=0.6 batch=1/GPU"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="sd15", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--nfe", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def make_solver(kind, name, cfg_name, nfe, batch, device):
+    from cfgpp_amd.unet_config import CONFIGS
+    cfg = CONFIGS[cfg_name]
+    sc = types.SimpleNamespace(num_sampling=nfe)
+    if kind == "sd":
+        from cfgpp_amd.latent_diffusion import get_solver
+    else:
+        from cfgpp_amd.latent_sdxl import get_solver
+    return get_solver(name, solver_config=sc, device=device, max_batch=batch), cfg
+
+
+def prompts_for(lo, hi):
+    base = ["a photo of an astronaut riding a horse on mars", "a watercolor painting of a lighthouse at dawn",
+            "a bowl of ramen on a wooden table, studio lighting", "a red fox in a snowy forest",
+            "an isometric render of a tiny city", "a portrait of an old sailor, oil on canvas",
+            "a macro shot of a dew drop on a leaf", "a futuristic train crossing a desert"]
+    return [f"{base[i % len(base)]} #{i}" for i in range(lo, hi)]
+
+
+NULL = "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,"
+
+
+def cpu_baseline(kind, name, cfg, nfe, lam, img, conds):
+    """The CPU restatement (oracle/) of the same path on the host cores: a bounded sample
+    (a few UNet + step iterations of ONE chain and one VAE decode), extrapolated."""
+    from cfgpp_amd.schedule import SchedulerTables
+    from cfgpp_amd.vae import TorchVAE
+    from cfgpp_amd.weights import synth_state_dict
+    from oracle import sampler as O
+    from oracle.unet_ref import UNetRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = UNetRef(cfg, synth_state_dict(cfg, 0))
+    tb = SchedulerTables(nfe)
+    hw = img // 8
+    z = torch.randn(1, 4, hw, hw)
+    ehs, ack = conds
+
+    def unet(zz, t):
+        eps = net(torch.cat([zz, zz]), float(t), ehs, ack)["sample"].half()
+        return eps[:1], eps[1:]
+    ts = tb.timesteps
+    unet(z, ts[0])                          # warm-up (thread pool, allocator)
+    n_iter = 2
+    t0 = time.time()
+    zt = z
+    for t in ts[:n_iter]:
+        eu, ec = unet(zt, t)
+        _, zt = O.ddim_step(zt, eu, ec, lam, None, None, False, True, sqrt4=tb.ddim_sqrt_coeffs(t))
+    s_per_iter = (time.time() - t0) / n_iter
+    vae = TorchVAE(cfg.vae_scale, device="cpu", dtype=torch.float32)
+    t0 = time.time()
+    vae.decode(zt)
+    dec_s = time.time() - t0
+    n_unet = nfe * (2 if "inversion" in name else 1)
+    total = n_unet * s_per_iter + dec_s
+    return {"value": round(1.0 / total, 6), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_iter} UNet(batch 2)+step iterations of one chain at {hw}x{hw} and one VAE decode, "
+                      f"timed ({s_per_iter:.2f} s/iter, decode {dec_s:.2f} s) and extrapolated to {n_unet} iterations"}
+
+
+def main():
+    args = parse()
+    from cfgpp_amd import dist as D
+    rank, local_rank, world = D.init()
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    kind, name, cfg_name, nfe, lam, B, img, desc = WORKLOADS[args.config]
+    B = args.batch or B
+    nfe = args.nfe or nfe
+    solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
+    eng = solver.engine
+
+    # ---- conditioning: rank 0 "encodes" every prompt, ONE broadcast of the packed block ----
+    total = B * world
+    D_ = cfg.cross_attention_dim
+    shapes = [((1, 77, D_), torch.float16), ((total, 77, D_), torch.float16)]
+    if kind == "xl":
+        shapes += [((1, cfg.addition_pooled_dim), torch.float16), ((total, cfg.addition_pooled_dim), torch.float16)]
+    payload = [None] * len(shapes)
+    if rank == 0:
+        if kind == "sd":
+            uc, c = solver.get_text_embed(NULL, prompts_for(0, total))
+            payload = [uc, c]
+        else:
+            p = prompts_for(0, total)
+            ne, pe, pn, pp = solver.get_text_embed(NULL, p, NULL, p)
+            payload = [ne, pe, pn, pp]
+    cond = D.broadcast_conditioning(payload, shapes, dev)
+    lo, hi = D.shard_range(total, rank, world)
+    seeds = [42 + i for i in range(lo, hi)]
+    src_latent = None
+    if "inversion" in name:
+        g = torch.Generator().manual_seed(7)
+        src_latent = (torch.randn((B, 4, img // 8, img // 8), generator=g) * cfg.vae_scale * 5).to(dev)
+
+    def one_job():
+        if kind == "sd":
+            return solver.sample(cfg_guidance=lam, prompt=None, prompt_embeds=(cond[0], cond[1][lo:hi].contiguous()), seeds=seeds)
+        pe = (cond[0], cond[1][lo:hi].contiguous(), cond[2], cond[3][lo:hi].contiguous())
+        if "inversion" in name:
+            pe = (pe[0], pe[1], pe[1], pe[2], pe[3], pe[3])
+            return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_latent=src_latent)
+        return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), seeds=seeds)
+
+    for _ in range(args.warmup):
+        out = one_job()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_job()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (B, 3, img, img) and bool(torch.isfinite(out).all())
+
+    images = total * args.steps
+    value = images / dt
+    n_unet = nfe * (2 if "inversion" in name else 1)
+    rows = 2 * B
+    unet_flops = eng.flops_per_forward(rows)          # algorithmic, per forward at this batch
+    flops_per_image = (n_unet * unet_flops / B) + VAE_DEC_FLOPS[img] + (VAE_ENC_FLOPS[img] if "inversion" in name else 0.0)
+    result = {
+        "metric": "images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": desc, "per_gpu_batch": B, "global_batch": total, "nfe": nfe, "lambda": lam,
+                   "unet_batch_rows": rows, "includes": "UNet + fused CFG++ step x NFE, VAE decode (torch-ROCm, interim), D2H copy",
+                   "weights": "seeded synthetic, exact diffusers shapes", "flops_per_image": flops_per_image,
+                   "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
+    }
+    if rank == 0 and not args.no_profile:
+        # dominant kernel = the implicit-GEMM conv/linear kernel: algorithmic FLOPs of its launches in one
+        # forward / their summed HIP-event durations on the launch stream (a profile pass right after the timed region)
+        z = torch.randn((B, 4, eng.H, eng.W), device=dev)
+        agg = None
+        for t in (981.0, 501.0, 21.0):
+            pr = eng.unet.profile(z, t)
+            if agg is None:
+                agg = pr
+            else:
+                for k in agg:
+                    agg[k]["ms"] += pr[k]["ms"]
+                    agg[k]["flops"] += pr[k]["flops"]
+        ig = agg["igemm"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/linear)", "achieved": round(ach, 1),
+                              "peak": PEAK_MFMA_FP16 / 1e12, "unit": "TFLOP/s", "frac": round(ach / (PEAK_MFMA_FP16 / 1e12), 4),
+                              "traffic": None, "launches_per_forward": ig["launches"],
+                              "avg_launch_us": round(ig["ms"] / 3 / max(ig["launches"], 1) * 1e3, 2),
+                              "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in agg.items()},
+                              "attention_TFLOPs": round(agg["attention"]["flops"] / (agg["attention"]["ms"] * 1e-3) / 1e12, 1)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if kind == "sd":
+            conds = (torch.cat([cond[0], cond[1][:1]]).float().cpu(), None)
+        else:
+            ack = {"text_embeds": torch.cat([cond[2], cond[3][:1]]).float().cpu(),
+                   "time_ids": torch.tensor([[img, img, 0, 0, img, img]] * 2, dtype=torch.float32)}
+            conds = (torch.cat([cond[0], cond[1][:1]]).float().cpu(), ack)
+        try:
+            result["cpu_baseline"] = cpu_baseline(kind, name, cfg, nfe, lam, img, conds)
+        except Exception as e:  # noqa: BLE001
+            result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

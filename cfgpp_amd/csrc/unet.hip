@@ -52,6 +52,13 @@ struct cfgpp_unet {
 
     std::vector<Op> plan;           // forward
     std::vector<Op> ctx_plan;       // set_context (cross-attention K/V, added-condition embedding)
+    // per-op tags of `plan` for the profiler: kernel family + algorithmic MACs per batch row
+    std::vector<int> plan_kind;     // 0 igemm (conv/linear), 1 attention, 2 norm (GN/LN), 3 small
+    std::vector<double> plan_macs;
+    void tag(int kind, double macs) {
+        plan_kind.resize(plan.size(), 3); plan_macs.resize(plan.size(), 0.0);
+        if (!plan.empty()) { plan_kind.back() = kind; plan_macs.back() = macs; }
+    }
 
     // activation pool, keyed by shape (halo stays zero for ever)
     std::map<std::tuple<int, int, int>, std::vector<half_t*>> pool;
@@ -280,6 +287,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * 9.0 * src.C;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * 9.0 * src.C);
     }
     // 1x1 conv over (src0 || src1) padded -> padded
     void conv1x1(const Tensor& s0, const Tensor* s1, const Tensor& dst, const half_t* w, const float* bias) {
@@ -290,6 +298,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * a.K;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * a.K);
     }
     // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
     void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
@@ -300,6 +309,7 @@ struct Plan {
         a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
         u->macs_per_row += (double)tokens * N * K;
         ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)tokens * N * K);
     }
     // tokens -> padded NHWC with residual from a padded tensor (Transformer2D proj_out)
     void linear_to_padded(const half_t* A, int K, const Tensor& dst, const half_t* w, const float* bias, const Tensor& resid) {
@@ -310,6 +320,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * K;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * K);
     }
     // projection into head-major buffers
     void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
@@ -321,6 +332,7 @@ struct Plan {
         a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
         if (count) u->macs_per_row += (double)tokens * N * K;
         ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, count ? (double)tokens * N * K : 0.0);
     }
     void groupnorm(const Tensor& s0, const Tensor* s1, half_t* dst, bool dst_padded, const float* g, const float* b,
                    float eps, bool silu) {
@@ -331,9 +343,11 @@ struct Plan {
             return cfgpp_op_groupnorm(p0, p1, dst, g, b, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
                                       dst_padded ? 1 : 0, s);
         });
+        if (ops == &u->plan) u->tag(2, 0.0);
     }
     void layernorm(const half_t* x, half_t* y, const float* g, const float* b, int tokens, int C) {
         ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_layernorm(x, y, g, b, (long)rows * tokens, C, 1e-5f, s); });
+        if (ops == &u->plan) u->tag(2, 0.0);
     }
     void attention(const half_t* q, const half_t* k, const half_t* vt, half_t* o, int nheads, int d, int nq, int nk,
                    int q_tok_pad, int k_tok_pad) {
@@ -341,6 +355,7 @@ struct Plan {
         ops->push_back([=](hipStream_t s, int rows) {
             return cfgpp_op_attention(q, k, vt, o, rows, nheads, d, nq, nk, q_tok_pad, k_tok_pad, s);
         });
+        if (ops == &u->plan) u->tag(1, 2.0 * (double)nheads * nq * nk * d);
     }
 };
 
@@ -622,6 +637,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
                 u->plan.push_back([=](hipStream_t s, int rows) {
                     return cfgpp_op_attention(hq, ck, cvt, o, rows, nheads, d, tok, uu->ctx_tokens, q_pad, ck_pad, s);
                 });
+                u->tag(1, 2.0 * (double)nheads * tok * 77 * d);
             }
             P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
             // feed-forward (GEGLU)
@@ -724,6 +740,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
     CFGPP_REQUIRE(B.ok, "finalize: %s", B.err.c_str());
     CFGPP_REQUIRE(skips.empty(), "finalize: internal error, %d skips left", (int)skips.size());
     CFGPP_HIP_CHECK(hipDeviceSynchronize());
+    u->plan_kind.resize(u->plan.size(), 3); u->plan_macs.resize(u->plan.size(), 0.0);
     u->finalized = true;
     return 0;
 }
@@ -753,6 +770,34 @@ int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
     u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
     for (auto& op : u->plan) { int e = op((hipStream_t)stream, rows); if (e) return e; }
     return 0;
+}
+
+// One forward with a HIP event between every launch of the plan, on `stream` (the stream the
+// kernels run on).  out_ms[k] / out_flops[k] / out_launches[k], k = 0 igemm (conv/linear),
+// 1 attention, 2 norm (GroupNorm/LayerNorm), 3 small ops; flops are ALGORITHMIC (2*MAC).
+int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t, void* eps_out, int rows,
+                       void* stream, double* out_ms, double* out_flops, int* out_launches) {
+    CFGPP_REQUIRE(u && u->finalized && u->ctx_set, "profile: context not ready");
+    CFGPP_REQUIRE(z && eps_out && out_ms && out_flops && out_launches && rows == u->ctx_rows, "profile: bad args");
+    u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = u->plan.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) CFGPP_HIP_CHECK(hipEventCreate(&e));
+    CFGPP_HIP_CHECK(hipEventRecord(ev[0], s));
+    int rc = 0;
+    for (size_t i = 0; i < n && rc == 0; ++i) { rc = u->plan[i](s, rows); if (rc == 0 && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = -1; }
+    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = -1;
+    for (int k = 0; k < 4; ++k) { out_ms[k] = 0; out_flops[k] = 0; out_launches[k] = 0; }
+    if (rc == 0) {
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            const int k = u->plan_kind[i];
+            out_ms[k] += ms; out_flops[k] += 2.0 * u->plan_macs[i] * rows; out_launches[k] += 1;
+        }
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
 }
 
 double cfgpp_unet_flops(cfgpp_unet* u, int rows) {

@@ -1,0 +1,101 @@
+"""Multi-GPU layer: one process per GPU, prompts sharded over ranks, ONE broadcast
+of the shared conditioning, independent sampling chains, optional gather.
+
+The reference has no multi-GPU path at all (single process, single device:
+examples/text_to_img.py:16).  Sampling chains are independent units - nothing
+is exchanged inside the NFE loop - so the only collective is a broadcast of the
+conditioning block from rank 0 (RCCL over xGMI on the GPU box,
+``backend="nccl"``; ``gloo`` in the CPU tests) and, if the caller wants all
+results on one rank, a gather of the final latents / images.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if unset)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block partition [lo, hi) of n_items chains for this rank (sizes differ by <= 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_conditioning(tensors: Sequence[Optional[torch.Tensor]], shapes_dtypes, device, src: int = 0):
+    """Broadcast the conditioning block (null-prompt embeds, per-prompt embeds, pooled embeds,
+    time ids ...) from ``src`` to every rank.  ``shapes_dtypes`` = [(shape, dtype), ...] is known
+    on every rank (it only depends on the model and the number of prompts); non-src ranks pass
+    ``None`` tensors.  Payloads are packed into ONE flat byte buffer -> a single collective."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return [t.to(device) for t in tensors]
+    sizes = []
+    for shape, dtype in shapes_dtypes:
+        n = 1
+        for d in shape:
+            n *= d
+        sizes.append(n * torch.empty((), dtype=dtype).element_size())
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + ((s + 15) // 16) * 16)
+    buf = torch.zeros(offs[-1], dtype=torch.uint8, device=device)
+    if rank == src:
+        for t, o, s in zip(tensors, offs, sizes):
+            buf[o:o + s] = t.contiguous().to(device).view(torch.uint8).reshape(-1)
+    dist.broadcast(buf, src=src)
+    out = []
+    for (shape, dtype), o, s in zip(shapes_dtypes, offs, sizes):
+        out.append(buf[o:o + s].view(dtype).reshape(shape).clone())
+    return out
+
+
+def gather_rows(local: torch.Tensor, counts: List[int], dst: int = 0) -> Optional[torch.Tensor]:
+    """Gather per-rank result rows (latents or images) to ``dst`` in prompt order.
+    ``counts[r]`` = rows held by rank r (from :func:`shard_range`)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    rank = dist.get_rank()
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -101,6 +101,12 @@ int cfgpp_unet_set_context(cfgpp_unet* u, const void* ehs, int rows, int tokens,
 int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t,
                        void* eps_out, int rows, void* stream);
 
+/* Same forward with a HIP event between every launch (on `stream`): per kernel family
+ * k = 0 implicit-GEMM conv/linear, 1 attention, 2 GroupNorm/LayerNorm, 3 small ops:
+ * elapsed ms, algorithmic FLOPs and launch counts.  Used by bench.py's roofline block. */
+int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t, void* eps_out, int rows,
+                       void* stream, double* out_ms, double* out_flops, int* out_launches);
+
 /* Algorithmic FLOPs (2*MAC over conv/linear/attention matmuls) of one forward at `rows`. */
 double cfgpp_unet_flops(cfgpp_unet* u, int rows);
 /* Bytes of device memory held (weights + activations). */

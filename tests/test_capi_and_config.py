@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cfgpp.h declares; UNet config
+tables reproduce the published parameter totals; FLOP model matches SURVEY.md 8(d)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cfgpp_amd import _lib
+    from cfgpp_amd.build import build
+    build(verbose=False)
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "cfgpp.h")).read()
+    declared = set(re.findall(r"\b(cfgpp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cfgpp_unet_config"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/cfgpp.h but not exported"
+        assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == declared
+    assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
+
+
+def test_param_totals_match_published_sizes():
+    from cfgpp_amd.unet_config import SD15, SDXL, param_count
+    assert param_count(SD15) == 859_520_964       # 859.5 M
+    assert param_count(SDXL) == 2_567_463_684     # 2567.5 M
+
+
+def test_flop_model():
+    from cfgpp_amd.unet_config import SD15, SDXL, unet_flops_per_row
+    assert abs(unet_flops_per_row(SD15, 64, 64) / 1e12 - 0.800) < 0.01
+    assert abs(unet_flops_per_row(SDXL, 128, 128) / 1e12 - 6.71) < 0.05
+
+
+def test_synthetic_weights_are_deterministic_and_fp16_exact():
+    import torch
+    from cfgpp_amd.unet_config import TINY_SD, param_shapes
+    from cfgpp_amd.weights import synth_state_dict
+    a, b = synth_state_dict(TINY_SD, 0), synth_state_dict(TINY_SD, 0)
+    assert list(a) == list(param_shapes(TINY_SD))
+    for k in a:
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], a[k].half().float())
+    assert not torch.equal(a["conv_in.weight"], synth_state_dict(TINY_SD, 1)["conv_in.weight"])
+
+
+def test_oracle_unet_runs_and_is_finite():
+    import torch
+    from cfgpp_amd.unet_config import TINY_XL as cfg
+    from cfgpp_amd.weights import synth_state_dict
+    from oracle.unet_ref import UNetRef
+    net = UNetRef(cfg, synth_state_dict(cfg))
+    out = net(torch.randn(2, 4, 16, 16), 500.0, torch.randn(2, 77, cfg.cross_attention_dim) * 0.5,
+              {"text_embeds": torch.randn(1, cfg.addition_pooled_dim), "time_ids": torch.tensor([[128.0, 128, 0, 0, 128, 128]])})["sample"]
+    assert out.shape == (2, 4, 16, 16) and torch.isfinite(out).all()

@@ -1,0 +1,104 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32
+reference of the same op (tolerances: fp16 storage of inputs/outputs, fp32 accumulate)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REL = 1.5e-3        # rel-L2 bound for a single op (observed ~2-3e-4: fp16 output rounding)
+
+
+@pytest.fixture(scope="module")
+def diag():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import gpu_diag
+    return gpu_diag
+
+
+def _walk(res, path=""):
+    """yield (path, stats-dict) for every leaf that has rel_l2"""
+    if isinstance(res, dict) and "rel_l2" in res:
+        yield path, res
+    elif isinstance(res, dict):
+        for k, v in res.items():
+            yield from _walk(v, f"{path}/{k}")
+
+
+def _check(diag, fn, name, rel=REL):
+    fn()
+    r = diag.RESULTS[name]
+    assert "error" not in r, r.get("error")
+    leaves = list(_walk(r))
+    assert leaves, f"{name}: no results"
+    for path, st in leaves:
+        assert st["finite"], f"{name}{path} not finite"
+        assert st["rel_l2"] < rel, f"{name}{path}: rel-L2 {st['rel_l2']:.3e} (max_abs {st['max_abs']:.3e})"
+    return r
+
+
+def test_gemm_orientation(diag):
+    r = _check(diag, diag.t_gemm_t, "gemm_transpose_check", rel=1e-6)      # exact: asymmetric B, A = I
+    assert r["max_abs"] == 0.0
+
+
+def test_gemm_all_tile_configs(diag):
+    _check(diag, diag.t_gemm, "gemm_basic")
+
+
+def test_gemm_geglu_epilogue(diag):
+    _check(diag, diag.t_geglu, "gemm_geglu")
+
+
+def test_conv3x3_bias_temb_residual(diag):
+    r = _check(diag, diag.t_conv, "conv3x3")
+    assert all(v["halo_zero"] for v in r.values())
+
+
+def test_conv3x3_stride2(diag):
+    _check(diag, diag.t_conv_s2, "conv3x3_stride2")
+
+
+def test_conv3x3_fused_nearest_upsample(diag):
+    _check(diag, diag.t_conv_up, "conv3x3_upsample")
+
+
+def test_conv1x1_two_concatenated_sources(diag):
+    _check(diag, diag.t_conv1, "conv1x1_two_sources")
+
+
+def test_groupnorm_silu_concat(diag):
+    r = _check(diag, diag.t_gn, "groupnorm")
+    assert all(v.get("halo_zero", True) for v in r.values())
+
+
+def test_layernorm(diag):
+    _check(diag, diag.t_ln, "layernorm")
+
+
+def test_attention_self_and_cross(diag):
+    _check(diag, diag.t_attn, "attention")
+
+
+def test_heads_projection_scatter(diag):
+    diag.t_heads()
+    r = diag.RESULTS["heads_projection"]
+    assert "error" not in r, r.get("error")
+    assert r["pad_zero"]
+    for k in ("q", "k", "vt"):
+        assert r[k]["rel_l2"] < REL
+
+
+def test_conv_in_out(diag):
+    _check(diag, diag.t_cio, "conv_in_out")
+
+
+def test_sinusoid_and_skinny_gemm(diag):
+    _check(diag, diag.t_small, "sinusoid_skinny")
+
+
+def test_ddim_step_kernel_bit_exact_vs_reference_golden(diag):
+    diag.t_step()
+    r = diag.RESULTS["step_kernels_golden"]
+    assert "error" not in r, r.get("error")
+    assert r["mismatching_elements"] == 0 and r["steps"] == 50
