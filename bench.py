@@ -44,6 +44,14 @@ WORKLOADS = {
 }
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    if os.environ.get("CFGPP_BENCH_VERBOSE", "1") != "0":
+        print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,8 +139,10 @@ def main():
     kind, name, cfg_name, nfe, lam, B, img, desc = WORKLOADS[args.config]
     B = args.batch or B
     nfe = args.nfe or nfe
+    log(f"building engine {cfg_name} max_batch={B}")
     solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
     eng = solver.engine
+    log(f"engine ready, device memory {eng.unet.device_bytes() / 1e9:.2f} GB")
 
     # ---- conditioning: rank 0 "encodes" every prompt, ONE broadcast of the packed block ----
     total = B * world
@@ -166,8 +176,10 @@ def main():
             return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_latent=src_latent)
         return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), seeds=seeds)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         out = one_job()
+        torch.cuda.synchronize()
+        log(f"warmup job {i} done")
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -176,6 +188,7 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    log(f"timed region done: {dt:.2f}s for {args.steps} jobs")
     assert out.shape == (B, 3, img, img) and bool(torch.isfinite(out).all())
 
     images = total * args.steps
@@ -221,6 +234,7 @@ def main():
             ack = {"text_embeds": torch.cat([cond[2], cond[3][:1]]).float().cpu(),
                    "time_ids": torch.tensor([[img, img, 0, 0, img, img]] * 2, dtype=torch.float32)}
             conds = (torch.cat([cond[0], cond[1][:1]]).float().cpu(), ack)
+        log("cpu baseline ...")
         try:
             result["cpu_baseline"] = cpu_baseline(kind, name, cfg, nfe, lam, img, conds)
         except Exception as e:  # noqa: BLE001

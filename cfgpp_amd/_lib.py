@@ -50,7 +50,7 @@ PROTOTYPES = {
     "cfgpp_unet_finalize": (_I, [_P]),
     "cfgpp_unet_set_context": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "cfgpp_unet_forward": (_I, [_P, _P, _I, _I, _F, _P, _I, _P]),
-    "cfgpp_unet_profile": (_I, [_P, _P, _I, _I, _F, _P, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "cfgpp_unet_profile": (_I, [_P, _P, _I, _I, _F, _P, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, _L]),
     "cfgpp_unet_flops": (C.c_double, [_P, _I]),
     "cfgpp_unet_device_bytes": (C.c_double, [_P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
@@ -64,6 +64,7 @@ PROTOTYPES = {
     "cfgpp_op_igemm": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _I, _I, _I, _P]),
     "cfgpp_op_igemm_heads": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_igemm_force_config": (None, [_I]),
+    "cfgpp_igemm_set_staging": (None, [_I]),
 }
 
 _lib = None

@@ -20,7 +20,7 @@ SOURCES = [
     ("norm_kernels.hip", []),
     ("small_kernels.hip", []),
     ("igemm_kernel.hip", []),
-    ("attn_kernel.hip", []),
+    ("attn_kernel.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # scores are consumed by VALU: keep MFMA results in VGPRs
     ("unet.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

@@ -7,12 +7,14 @@
 // operand is a contiguous 8/16-byte LDS read and no cross-lane shuffles are needed:
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows = keys, B = Q^T cols =
 //     queries): each lane ends up holding 16 scores of ONE query per 32-key tile.
-//   * Online softmax entirely in registers (one __shfl_xor(…,32) for the row max).
+//   * Online softmax entirely in registers (one __shfl_xor(…,32) for the row max); Q is pre-scaled by
+//     d^-1/2*log2(e) so scores feed v_exp_f32 directly; the O rescale is skipped (exactly) on tiles
+//     where no query's running max grows; key masking only on a partial last tile.
 //   * O^T += V^T P^T: the B operand (P^T) is exactly the lane's own 8 consecutive
 //     accumulator registers converted to fp16 (the MFMA k-slot <-> key assignment is
 //     free as long as A and B agree), the A operand is 2 x ds_read_b64 from V^T.
-//   * 4 waves x 32 queries per workgroup, 64-key tiles, register-prefetched K/V
-//     tiles, padded LDS rows (conflict-free ds_read_b128).
+//   * 4 waves x 32 queries per workgroup, 64-key tiles, double-buffered LDS + register
+//     prefetch two tiles ahead (one barrier per tile), padded LDS rows (conflict-free ds_read_b128).
 // Cross-attention (77 keys padded to 128) uses the same kernel with nk_valid = 77.
 // softmax statistics and accumulation are fp32; P is rounded to fp16 for the PV
 // product (same as the reference's SDPA flash path under fp16 autocast).
@@ -37,10 +39,9 @@ attn_kernel(const AttnArgs a) {
     constexpr int KPITCH = DP * 2 + 16;          // bytes per K row in LDS
     constexpr int VPITCH = 64 * 2 + 16;          // bytes per V^T row in LDS (64 keys)
     constexpr int CH = (64 * DP / 8) / 256;      // 16-B chunks per thread per tile (K and V each)
+    constexpr int STAGE = 64 * KPITCH + DP * VPITCH;
     static_assert((64 * DP / 8) % 256 == 0, "tile/loader mismatch");
-    __shared__ __attribute__((aligned(16))) char smem[64 * KPITCH + DP * VPITCH];
-    char* Ks = smem;
-    char* Vs = smem + 64 * KPITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages of (K tile | V^T tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -50,11 +51,15 @@ attn_kernel(const AttnArgs a) {
     const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
     const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
 
-    // Q^T fragments (B operand): lane = query q0+l31, 8 consecutive d at ks*16 + hi*8
+    // Q^T fragments (B operand): lane = query q0+l31, 8 consecutive d at ks*16 + hi*8, pre-multiplied by
+    // d^-1/2 * log2(e) so that the scores come out of the MFMA ready for exp2.
     half8_t qf[D16];
 #pragma unroll
-    for (int ks = 0; ks < D16; ++ks)
-        qf[ks] = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
+    for (int ks = 0; ks < D16; ++ks) {
+        const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
+    }
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -64,9 +69,8 @@ attn_kernel(const AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (a.nk_valid + 63) >> 6;
+    const int tail = a.nk_valid & 63;            // != 0: the last tile is partially masked
 
-    // cooperative tile loaders: K tile = 64 rows x DP halfs, chunk id c -> (row = c / (DP/8), col8 = c % (DP/8))
-    //                           V tile = DP rows x 64 keys, chunk id c -> (row = c / 8, col8 = c % 8)
     half8_t rk[CH], rv[CH];
     auto load_tile = [&](int t) {
 #pragma unroll
@@ -78,7 +82,9 @@ attn_kernel(const AttnArgs a) {
             rv[j] = *reinterpret_cast<const half8_t*>(Vb + (long)vr * a.k_tok_pad + t * 64 + vc * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
+        char* Ks = smem + stage * STAGE;
+        char* Vs = Ks + 64 * KPITCH;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int c = tid + j * 256;
@@ -90,55 +96,65 @@ attn_kernel(const AttnArgs a) {
     };
 
     load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    if (ntiles > 1) load_tile(1);
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();            // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(t + 1);
+        const char* Ks = smem + (t & 1) * STAGE;
+        const char* Vs = Ks + 64 * KPITCH;
 
-        // ---- S^T = K Q^T for two 32-key sub-tiles ----
+        // ---- S^T = K Q^T for two 32-key sub-tiles (scores already in the log2 domain) ----
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 32 + l31) * KPITCH + (hi * 8) * 2);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], zero, 0, 0, 0);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < D16; ++ks) {
+            for (int ks = 1; ks < D16; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 32 + l31) * KPITCH + (ks * 16 + hi * 8) * 2);
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
             }
         }
-        // ---- online softmax (per query = per lane column; keys across regs and the two half-waves) ----
-        const int kbase = t * 64 + 4 * hi;
-        float mx = -INFINITY;
+        if (tail != 0 && t == ntiles - 1) {      // wave-uniform: mask keys >= nk_valid (cross-attention, 77 keys)
+            const int kbase = t * 64 + 4 * hi;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+                    s[kt][r] = key < a.nk_valid ? s[kt][r] : -INFINITY;
+                }
+        }
+        // ---- online softmax: per query = per lane column; keys across 32 registers and the two half-waves ----
+        float mx = s[0][0];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
-                float v = s[kt][r] * a.scale_log2e;
-                v = key < a.nk_valid ? v : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
-        m_run = m_new;
+        if (!__all(mx <= m_run)) {                // some query's max grew: rescale (exact; skipped otherwise)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[kt][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_run);
                 s[kt][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -161,6 +177,10 @@ attn_kernel(const AttnArgs a) {
                     oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
                 }
             }
+        // ---- stage tile t+1 (registers -> the other LDS stage), prefetch tile t+2 ----
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
+        if (t + 2 < ntiles) load_tile(t + 2);
     }
 
     // ---- finalize: O = O^T / l, store token-major ----
@@ -185,6 +205,20 @@ attn_kernel(const AttnArgs a) {
     }
 }
 
+template <int D16, int DT>
+int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int DP = DT * 32;
+    constexpr int smem = 2 * (64 * (DP * 2 + 16) + DP * (64 * 2 + 16));
+    static bool attr_set = false;
+    auto kern = attn_kernel<D16, DT>;
+    if (!attr_set) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,7 +240,7 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     hipStream_t s = (hipStream_t)stream;
     const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
 #define ATTN_CASE(D16_, DT_) \
-    if (d16 == D16_ && dt == DT_) { hipLaunchKernelGGL((attn_kernel<D16_, DT_>), grid, dim3(256), 0, s, a); } else
+    if (d16 == D16_ && dt == DT_) { if (launch_attn<D16_, DT_>(a, grid, s)) return -1; } else
     ATTN_CASE(1, 1) ATTN_CASE(2, 1) ATTN_CASE(3, 2) ATTN_CASE(4, 2) ATTN_CASE(5, 3) ATTN_CASE(6, 3)
     ATTN_CASE(8, 4) ATTN_CASE(10, 5)
     { cfgpp_set_error("attention: no kernel instance for head dim %d", d); return -2; }

@@ -32,7 +32,10 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
     return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
 }
 
-template <int WM, int WN, int WTM, int WTN>
+// GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
+// applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
+template <int WM, int WN, int WTM, int WTN, bool GLDS>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
     constexpr int NTHR = 64 * WM * WN;
@@ -81,12 +84,15 @@ igemm_kernel(const IGemmArgs p) {
             a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap
         }
     }
+    // source chunk: register staging loads logical chunk `lchunk` and swizzles the LDS store address;
+    // the DMA path stores linearly, so it loads the chunk that BELONGS at physical slot `lchunk`.
+    const int schunk = GLDS ? (lchunk ^ ((lrow >> 1) & 7)) : lchunk;
     const half_t* b_ptr[B_CH];
 #pragma unroll
     for (int j = 0; j < B_CH; ++j) {
         int n = n0 + lrow + j * RSTEP;
         n = n < p.N ? n : p.N - 1;
-        b_ptr[j] = p.w + (long)n * p.K + lchunk * 8;
+        b_ptr[j] = p.w + (long)n * p.K + schunk * 8;
     }
     // LDS store offsets (swizzled), identical for both operands
     int st_off[(A_CH > B_CH ? A_CH : B_CH)];
@@ -124,6 +130,41 @@ igemm_kernel(const IGemmArgs p) {
 #pragma unroll
         for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const half8_t*>(b_ptr[j] + ((long)kt << 6));
     };
+    // DMA variant: same addresses, destination = wave-uniform LDS base (+ lane*16 added by hardware)
+    const int wave_row0 = __builtin_amdgcn_readfirstlane(wid) * 8;
+    auto dma_tile = [&](int kt, int stage) {
+        const int tap = kt / tiles_per_tap;
+        const int cc = (kt - tap * tiles_per_tap) << 6;
+        const half_t* src; int cs, Cs;
+        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        int dpix = 0;
+        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
+        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int pix;
+            if (p.amode == 3) {
+                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
+            } else {
+                pix = a_pix[j] + dpix;
+            }
+            const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(As + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            const half_t* g = b_ptr[j] + ((long)kt << 6);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(Bs + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        }
+    };
     auto store_tile = [&](int stage) {
         char* As = smem + stage * STAGE_BYTES;
         char* Bs = As + BM * 128;
@@ -147,12 +188,19 @@ igemm_kernel(const IGemmArgs p) {
     const int a_rd = (wm * WTM + frow) * 128;
     const int b_rd = (wn * WTN + frow) * 128;
 
-    load_tile(0);
-    store_tile(0);
+    if constexpr (GLDS) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if (kt + 1 < KT) {
+            if constexpr (GLDS) dma_tile(kt + 1, cur ^ 1); else load_tile(kt + 1);
+        }
         const char* As = smem + cur * STAGE_BYTES;
         const char* Bs = As + BM * 128;
 #pragma unroll
@@ -169,7 +217,11 @@ igemm_kernel(const IGemmArgs p) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
+        } else {
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+        }
         __syncthreads();
     }
 
@@ -276,12 +328,12 @@ igemm_kernel(const IGemmArgs p) {
     }
 }
 
-template <int WM, int WN, int WTM, int WTN>
+template <int WM, int WN, int WTM, int WTN, bool GLDS>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -295,9 +347,12 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// forced tile config for tests / tuning: 0 = heuristic
+// forced tile config for tests / tuning: 0 = heuristic; 1..3 tile shapes; +10 = register-staged
+// variant of the same tile (the LDS-DMA variant is the default)
 static int g_force_cfg = 0;
+static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
+extern "C" void cfgpp_igemm_set_staging(int glds) { g_staging = glds ? 1 : 0; }
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
     const int Cin = a.C0 + a.C1;
@@ -322,10 +377,12 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         else cfg = 3;
         if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
     }
+    bool glds = g_staging != 0;
+    if (cfg > 10) { cfg -= 10; glds = false; }
     switch (cfg) {
-        case 1: return launch_cfg<2, 2, 64, 64>(a, stream);
-        case 2: return launch_cfg<4, 1, 64, 64>(a, stream);
-        case 3: return launch_cfg<2, 2, 32, 32>(a, stream);
+        case 1: return glds ? launch_cfg<2, 2, 64, 64, true>(a, stream) : launch_cfg<2, 2, 64, 64, false>(a, stream);
+        case 2: return glds ? launch_cfg<4, 1, 64, 64, true>(a, stream) : launch_cfg<4, 1, 64, 64, false>(a, stream);
+        case 3: return glds ? launch_cfg<2, 2, 32, 32, true>(a, stream) : launch_cfg<2, 2, 32, 32, false>(a, stream);
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }

@@ -55,9 +55,10 @@ struct cfgpp_unet {
     // per-op tags of `plan` for the profiler: kernel family + algorithmic MACs per batch row
     std::vector<int> plan_kind;     // 0 igemm (conv/linear), 1 attention, 2 norm (GN/LN), 3 small
     std::vector<double> plan_macs;
-    void tag(int kind, double macs) {
-        plan_kind.resize(plan.size(), 3); plan_macs.resize(plan.size(), 0.0);
-        if (!plan.empty()) { plan_kind.back() = kind; plan_macs.back() = macs; }
+    std::vector<std::string> plan_desc;
+    void tag(int kind, double macs, const std::string& desc = "") {
+        plan_kind.resize(plan.size(), 3); plan_macs.resize(plan.size(), 0.0); plan_desc.resize(plan.size());
+        if (!plan.empty()) { plan_kind.back() = kind; plan_macs.back() = macs; plan_desc.back() = desc; }
     }
 
     // activation pool, keyed by shape (halo stays zero for ever)
@@ -287,7 +288,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * 9.0 * src.C;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
-        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * 9.0 * src.C);
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * 9.0 * src.C, "conv3x3 amode=" + std::to_string(amode) + " HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(9 * src.C) + (resid ? " +res" : "") + (temb ? " +temb" : ""));
     }
     // 1x1 conv over (src0 || src1) padded -> padded
     void conv1x1(const Tensor& s0, const Tensor* s1, const Tensor& dst, const half_t* w, const float* bias) {
@@ -298,7 +299,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * a.K;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
-        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * a.K);
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * a.K, "conv1x1 HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(a.K));
     }
     // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
     void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
@@ -309,7 +310,7 @@ struct Plan {
         a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
         u->macs_per_row += (double)tokens * N * K;
         ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
-        if (ops == &u->plan) u->tag(0, (double)tokens * N * K);
+        if (ops == &u->plan) u->tag(0, (double)tokens * N * K, std::string(epi == EPI_GEGLU ? "geglu" : "linear") + " HW=" + std::to_string(tokens) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + (resid ? " +res" : ""));
     }
     // tokens -> padded NHWC with residual from a padded tensor (Transformer2D proj_out)
     void linear_to_padded(const half_t* A, int K, const Tensor& dst, const half_t* w, const float* bias, const Tensor& resid) {
@@ -320,7 +321,7 @@ struct Plan {
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * K;
         ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
-        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * K);
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * K, "proj_out HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(K));
     }
     // projection into head-major buffers
     void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
@@ -332,7 +333,7 @@ struct Plan {
         a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
         if (count) u->macs_per_row += (double)tokens * N * K;
         ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
-        if (ops == &u->plan) u->tag(0, count ? (double)tokens * N * K : 0.0);
+        if (ops == &u->plan) u->tag(0, count ? (double)tokens * N * K : 0.0, "heads HW=" + std::to_string(tokens) + " N=" + std::to_string(N) + " K=" + std::to_string(K));
     }
     void groupnorm(const Tensor& s0, const Tensor* s1, half_t* dst, bool dst_padded, const float* g, const float* b,
                    float eps, bool silu) {
@@ -343,11 +344,11 @@ struct Plan {
             return cfgpp_op_groupnorm(p0, p1, dst, g, b, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
                                       dst_padded ? 1 : 0, s);
         });
-        if (ops == &u->plan) u->tag(2, 0.0);
+        if (ops == &u->plan) u->tag(2, 0.0, "groupnorm HW=" + std::to_string(H * W) + " C=" + std::to_string(C0 + C1));
     }
     void layernorm(const half_t* x, half_t* y, const float* g, const float* b, int tokens, int C) {
         ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_layernorm(x, y, g, b, (long)rows * tokens, C, 1e-5f, s); });
-        if (ops == &u->plan) u->tag(2, 0.0);
+        if (ops == &u->plan) u->tag(2, 0.0, "layernorm HW=" + std::to_string(tokens) + " C=" + std::to_string(C));
     }
     void attention(const half_t* q, const half_t* k, const half_t* vt, half_t* o, int nheads, int d, int nq, int nk,
                    int q_tok_pad, int k_tok_pad) {
@@ -355,7 +356,7 @@ struct Plan {
         ops->push_back([=](hipStream_t s, int rows) {
             return cfgpp_op_attention(q, k, vt, o, rows, nheads, d, nq, nk, q_tok_pad, k_tok_pad, s);
         });
-        if (ops == &u->plan) u->tag(1, 2.0 * (double)nheads * nq * nk * d);
+        if (ops == &u->plan) u->tag(1, 2.0 * (double)nheads * nq * nk * d, "self_attn heads=" + std::to_string(nheads) + " N=" + std::to_string(nq) + " d=" + std::to_string(d));
     }
 };
 
@@ -637,7 +638,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
                 u->plan.push_back([=](hipStream_t s, int rows) {
                     return cfgpp_op_attention(hq, ck, cvt, o, rows, nheads, d, tok, uu->ctx_tokens, q_pad, ck_pad, s);
                 });
-                u->tag(1, 2.0 * (double)nheads * tok * 77 * d);
+                u->tag(1, 2.0 * (double)nheads * tok * 77 * d, "cross_attn heads=" + std::to_string(nheads) + " N=" + std::to_string(tok) + " d=" + std::to_string(d));
             }
             P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
             // feed-forward (GEGLU)
@@ -740,7 +741,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
     CFGPP_REQUIRE(B.ok, "finalize: %s", B.err.c_str());
     CFGPP_REQUIRE(skips.empty(), "finalize: internal error, %d skips left", (int)skips.size());
     CFGPP_HIP_CHECK(hipDeviceSynchronize());
-    u->plan_kind.resize(u->plan.size(), 3); u->plan_macs.resize(u->plan.size(), 0.0);
+    u->plan_kind.resize(u->plan.size(), 3); u->plan_macs.resize(u->plan.size(), 0.0); u->plan_desc.resize(u->plan.size());
     u->finalized = true;
     return 0;
 }
@@ -776,7 +777,7 @@ int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
 // kernels run on).  out_ms[k] / out_flops[k] / out_launches[k], k = 0 igemm (conv/linear),
 // 1 attention, 2 norm (GroupNorm/LayerNorm), 3 small ops; flops are ALGORITHMIC (2*MAC).
 int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t, void* eps_out, int rows,
-                       void* stream, double* out_ms, double* out_flops, int* out_launches) {
+                       void* stream, double* out_ms, double* out_flops, int* out_launches, char* detail, long detail_cap) {
     CFGPP_REQUIRE(u && u->finalized && u->ctx_set, "profile: context not ready");
     CFGPP_REQUIRE(z && eps_out && out_ms && out_flops && out_launches && rows == u->ctx_rows, "profile: bad args");
     u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
@@ -794,6 +795,18 @@ int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
             float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             const int k = u->plan_kind[i];
             out_ms[k] += ms; out_flops[k] += 2.0 * u->plan_macs[i] * rows; out_launches[k] += 1;
+        }
+        if (detail && detail_cap > 0) {      // one line per launch: index, family, description, us, GFLOP
+            std::string txt;
+            for (size_t i = 0; i < n; ++i) {
+                float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+                char line[256];
+                snprintf(line, sizeof(line), "%zu\t%d\t%s\t%.1f\t%.3f\n", i, u->plan_kind[i], u->plan_desc[i].c_str(), ms * 1e3,
+                         2.0 * u->plan_macs[i] * rows * 1e-9);
+                txt += line;
+            }
+            const long ncopy = std::min<long>((long)txt.size(), detail_cap - 1);
+            std::memcpy(detail, txt.data(), ncopy); detail[ncopy] = 0;
         }
     }
     for (auto& e : ev) hipEventDestroy(e);

@@ -194,16 +194,21 @@ class HipUNet:
                                           eps_out.data_ptr(), rows, _stream_ptr()), "cfgpp_unet_forward")
         return eps_out
 
-    def profile(self, z: torch.Tensor, t: float) -> dict:
+    def profile(self, z: torch.Tensor, t: float, detail: bool = False) -> dict:
         """One forward with HIP events between launches: per kernel family ms / algorithmic flops / launches."""
         _require_cuda(z, "z")
         rows = self.rows
         eps = torch.empty((rows, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=z.device)
         ms, fl, ln = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int * 4)()
+        buf = C.create_string_buffer(1 << 20) if detail else None
         check(self.lib.cfgpp_unet_profile(self._h, z.data_ptr(), 1 if z.dtype == torch.float16 else 0, int(z.shape[0]),
-                                          float(t), eps.data_ptr(), rows, _stream_ptr(), ms, fl, ln), "cfgpp_unet_profile")
+                                          float(t), eps.data_ptr(), rows, _stream_ptr(), ms, fl, ln, buf, (1 << 20) if detail else 0),
+              "cfgpp_unet_profile")
         names = ("igemm", "attention", "norm", "small")
-        return {n: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i, n in enumerate(names)}
+        out = {n: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i, n in enumerate(names)}
+        if detail:
+            out["detail"] = buf.value.decode()
+        return out
 
     def flops(self, rows: int) -> float:
         return float(self.lib.cfgpp_unet_flops(self._h, int(rows)))

@@ -12,6 +12,8 @@ B independent chains; chain b equals the reference run with ``set_seed(s_b)``.
 """
 from __future__ import annotations
 
+import os
+import sys
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
@@ -243,6 +245,9 @@ class StableDiffusion:
         return self._ddim_inversion(z0, uc, c, cfg_guidance, cfgpp=False)
 
     def _finish(self, z):
+        if os.environ.get("CFGPP_TRACE"):
+            torch.cuda.synchronize() if z.is_cuda else None
+            print("[cfgpp] sampling loop done, decoding", file=sys.stderr, flush=True)
         img = self.decode(z)
         img = (img / 2 + 0.5).clamp(0, 1)
         return img.detach().cpu()

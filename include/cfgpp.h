@@ -105,7 +105,8 @@ int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
  * k = 0 implicit-GEMM conv/linear, 1 attention, 2 GroupNorm/LayerNorm, 3 small ops:
  * elapsed ms, algorithmic FLOPs and launch counts.  Used by bench.py's roofline block. */
 int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t, void* eps_out, int rows,
-                       void* stream, double* out_ms, double* out_flops, int* out_launches);
+                       void* stream, double* out_ms, double* out_flops, int* out_launches,
+                       char* detail /* optional: one text line per launch */, long detail_cap);
 
 /* Algorithmic FLOPs (2*MAC over conv/linear/attention matmuls) of one forward at `rows`. */
 double cfgpp_unet_flops(cfgpp_unet* u, int rows);
@@ -142,7 +143,8 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
-void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64 */
+void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64; +10 = register-staged variant */
+void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,31 @@
+"""Per-launch profile of one UNet forward, aggregated by (family, shape): python scripts/profile_unet.py sd15 16"""
+import os, sys, collections, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from cfgpp_amd.hip_engine import HipEngine
+from cfgpp_amd import _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "sd15"
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+hw = int(sys.argv[3]) if len(sys.argv) > 3 else None
+staging = int(os.environ.get("STAGING", "1"))
+_lib.load().cfgpp_igemm_set_staging(staging)
+eng = HipEngine(name, max_batch=rows // 2, latent_hw=(hw, hw) if hw else None)
+cfg = eng.cfg
+B = rows // 2
+uc = torch.randn(1, 77, cfg.cross_attention_dim).half() * 0.5; c = torch.randn(B, 77, cfg.cross_attention_dim).half() * 0.5
+te = ti = None
+if cfg.addition_embed:
+    te = torch.randn(rows, cfg.addition_pooled_dim).half() * 0.5; ti = torch.tensor([[1024., 1024, 0, 0, 1024, 1024]] * rows)
+eng.set_context(uc.cuda(), c.cuda(), te, ti)
+z = torch.randn(B, 4, eng.H, eng.W, device="cuda")
+for _ in range(2): eng.predict(z, 500.0)
+agg = collections.OrderedDict()
+N = 3
+for _ in range(N):
+    pr = eng.unet.profile(z, 500.0, detail=True)
+    for line in pr["detail"].strip().split("\n"):
+        i, kind, desc, us, gf = line.split("\t")
+        a = agg.setdefault((kind, desc), [0, 0.0, 0.0]); a[0] += 1; a[1] += float(us); a[2] += float(gf)
+tot = sum(a[1] for a in agg.values()) / N
+print(f"# {name} rows={rows} staging={'glds' if staging else 'reg'} total {tot/1e3:.2f} ms/forward")
+for (kind, desc), (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"{us/N/1e3:8.3f} ms  {100*us/N/tot:5.1f}%  x{cnt//N:<3d} {gf/us*1e3 if us else 0:7.1f} TF/s  [{kind}] {desc}")
