@@ -37,6 +37,10 @@ struct IGemmArgs {
     int head_dim, head_dim_pad, heads;
     int tok_pad;              // padded token count of K rows / V^T columns (>= rows_per_batch)
     int q_tok_pad;            // padded token count of Q rows
+    // ---- tile scheduling (filled by igemm_launch) ----
+    int n_main;               // tiles [0, n_main) are computed whole by one block each
+    int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
+    float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);

@@ -32,202 +32,11 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
     return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
 }
 
-// GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
-// ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
-// applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
-template <int WM, int WN, int WTM, int WTN, bool GLDS>
-__global__ void __launch_bounds__(64 * WM * WN)
-igemm_kernel(const IGemmArgs p) {
-    constexpr int NTHR = 64 * WM * WN;
-    constexpr int BM = WM * WTM, BN = WN * WTN;
-    constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
-    constexpr int A_CH = BM / RSTEP, B_CH = BN / RSTEP;
-    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0, "tile/loader mismatch");
-    constexpr int STAGE_BYTES = (BM + BN) * 128;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // ---- workgroup -> tile, XCD-aware (block b runs on XCD b % 8) ----
-    const int ntn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid - wm * WN;
-
-    // ---- loader state ----
-    const int lrow = tid >> 3, lchunk = tid & 7;
-    const int HW = p.rows_per_batch;
-    const int Cin = p.C0 + p.C1;
-    const int tiles_per_tap = Cin >> 6;
-    int a_pix[A_CH];
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) {
-        int m = m0 + lrow + j * RSTEP;
-        m = m < p.M ? m : p.M - 1;
-        if (p.amode == 0) a_pix[j] = m;
-        else if (p.amode == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
-        else if (p.amode == 2) {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
-            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1) * (2 * p.W + 2) + 2 * x + 1;
-        } else {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
-            a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap
-        }
-    }
-    // source chunk: register staging loads logical chunk `lchunk` and swizzles the LDS store address;
-    // the DMA path stores linearly, so it loads the chunk that BELONGS at physical slot `lchunk`.
-    const int schunk = GLDS ? (lchunk ^ ((lrow >> 1) & 7)) : lchunk;
-    const half_t* b_ptr[B_CH];
-#pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-        int n = n0 + lrow + j * RSTEP;
-        n = n < p.N ? n : p.N - 1;
-        b_ptr[j] = p.w + (long)n * p.K + schunk * 8;
-    }
-    // LDS store offsets (swizzled), identical for both operands
-    int st_off[(A_CH > B_CH ? A_CH : B_CH)];
-#pragma unroll
-    for (int j = 0; j < (A_CH > B_CH ? A_CH : B_CH); ++j) {
-        const int r = lrow + j * RSTEP;
-        st_off[j] = r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4);
-    }
-
-    half8_t ra[A_CH], rb[B_CH];
-    const int KT = p.K >> 6;
-
-    auto load_tile = [&](int kt) {
-        const int tap = kt / tiles_per_tap;
-        const int cc = (kt - tap * tiles_per_tap) << 6;
-        const half_t* src; int cs, Cs;
-        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
-        int dy = 0, dx = 0;
-        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        int dpix = 0;
-        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
-        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
-#pragma unroll
-        for (int j = 0; j < A_CH; ++j) {
-            int pix;
-            if (p.amode == 3) {
-                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
-                const int Hs = p.H >> 1, Ws = p.W >> 1;
-                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
-            } else {
-                pix = a_pix[j] + dpix;
-            }
-            ra[j] = *reinterpret_cast<const half8_t*>(src + (long)pix * Cs + cs + lchunk * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const half8_t*>(b_ptr[j] + ((long)kt << 6));
-    };
-    // DMA variant: same addresses, destination = wave-uniform LDS base (+ lane*16 added by hardware)
-    const int wave_row0 = __builtin_amdgcn_readfirstlane(wid) * 8;
-    auto dma_tile = [&](int kt, int stage) {
-        const int tap = kt / tiles_per_tap;
-        const int cc = (kt - tap * tiles_per_tap) << 6;
-        const half_t* src; int cs, Cs;
-        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
-        int dy = 0, dx = 0;
-        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        int dpix = 0;
-        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
-        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
-        char* As = smem + stage * STAGE_BYTES;
-        char* Bs = As + BM * 128;
-#pragma unroll
-        for (int j = 0; j < A_CH; ++j) {
-            int pix;
-            if (p.amode == 3) {
-                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
-                const int Hs = p.H >> 1, Ws = p.W >> 1;
-                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
-            } else {
-                pix = a_pix[j] + dpix;
-            }
-            const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(As + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) {
-            const half_t* g = b_ptr[j] + ((long)kt << 6);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(Bs + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* As = smem + stage * STAGE_BYTES;
-        char* Bs = As + BM * 128;
-#pragma unroll
-        for (int j = 0; j < A_CH; ++j) *reinterpret_cast<half8_t*>(As + st_off[j]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) *reinterpret_cast<half8_t*>(Bs + st_off[j]) = rb[j];
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-
-    // fragment read offsets: row = base + (lane&31), logical chunk = ks*2 + (lane>>5)
+// Shared epilogue.  lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
+template <int MT, int NT>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane) {
     const int frow = lane & 31, fhi = lane >> 5;
-    const int fsw = (frow >> 1) & 7;
-    const int a_rd = (wm * WTM + frow) * 128;
-    const int b_rd = (wn * WTN + frow) * 128;
-
-    if constexpr (GLDS) {
-        dma_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) {
-            if constexpr (GLDS) dma_tile(kt + 1, cur ^ 1); else load_tile(kt + 1);
-        }
-        const char* As = smem + cur * STAGE_BYTES;
-        const char* Bs = As + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
-            half8_t xa[MT], wb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-        }
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
-        } else {
-            if (kt + 1 < KT) store_tile(cur ^ 1);
-        }
-        __syncthreads();
-    }
-
-    // ---------------------------------------------------------------- epilogue
-    // lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
-    const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+    const int HW = p.rows_per_batch;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = mw0 + i * 32 + frow;
@@ -328,10 +137,265 @@ igemm_kernel(const IGemmArgs p) {
     }
 }
 
+// GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
+// ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
+// applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 template <int WM, int WN, int WTM, int WTN, bool GLDS>
-int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
+__global__ void __launch_bounds__(64 * WM * WN)
+igemm_kernel(const IGemmArgs p) {
+    constexpr int NTHR = 64 * WM * WN;
     constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
+    constexpr int A_CH = BM / RSTEP, B_CH = BN / RSTEP;
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0, "tile/loader mismatch");
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- workgroup -> (tile, k-range).  Blocks [0, n_main) own one whole tile each (XCD-aware order:
+    // block b runs on XCD b % 8, consecutive tiles share activation rows).  Blocks >= n_main are the
+    // K-split TAIL: tile n_main + b/ksplit, k-slice b % ksplit; they write fp32 partials that
+    // igemm_reduce_kernel finishes.  (Tile quantisation, not the inner loop, is what the profile showed
+    // to cost most: e.g. 640 tiles on 512 resident slots, or 80 tiles on 256 CUs.)
+    const int ntn = (p.N + BN - 1) / BN;
+    const int bid = blockIdx.x;
+    int wg, ksl = 0;
+    const bool is_tail = bid >= p.n_main;
+    if (!is_tail) {
+        const int nwg = p.n_main;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    } else {
+        const int b2 = bid - p.n_main;
+        wg = p.n_main + b2 / p.ksplit;
+        ksl = b2 - (b2 / p.ksplit) * p.ksplit;
+    }
+    const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+
+    // ---- loader state ----
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int HW = p.rows_per_batch;
+    const int Cin = p.C0 + p.C1;
+    const int tiles_per_tap = Cin >> 6;
+    int a_pix[A_CH];
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+        int m = m0 + lrow + j * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        if (p.amode == 0) a_pix[j] = m;
+        else if (p.amode == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
+        else if (p.amode == 2) {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1) * (2 * p.W + 2) + 2 * x + 1;
+        } else {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap
+        }
+    }
+    // source chunk: register staging loads logical chunk `lchunk` and swizzles the LDS store address;
+    // the DMA path stores linearly, so it loads the chunk that BELONGS at physical slot `lchunk`.
+    const int schunk = GLDS ? (lchunk ^ ((lrow >> 1) & 7)) : lchunk;
+    const half_t* b_ptr[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        int n = n0 + lrow + j * RSTEP;
+        n = n < p.N ? n : p.N - 1;
+        b_ptr[j] = p.w + (long)n * p.K + schunk * 8;
+    }
+    // LDS store offsets (swizzled), identical for both operands
+    int st_off[(A_CH > B_CH ? A_CH : B_CH)];
+#pragma unroll
+    for (int j = 0; j < (A_CH > B_CH ? A_CH : B_CH); ++j) {
+        const int r = lrow + j * RSTEP;
+        st_off[j] = r * 128 + ((lchunk ^ ((r >> 1) & 7)) << 4);
+    }
+
+    half8_t ra[A_CH], rb[B_CH];
+    const int KT_all = p.K >> 6;
+    const int kt_begin = is_tail ? (int)(((long)ksl * KT_all) / p.ksplit) : 0;
+    const int kt_end = is_tail ? (int)(((long)(ksl + 1) * KT_all) / p.ksplit) : KT_all;
+
+    auto load_tile = [&](int kt) {
+        const int tap = kt / tiles_per_tap;
+        const int cc = (kt - tap * tiles_per_tap) << 6;
+        const half_t* src; int cs, Cs;
+        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        int dpix = 0;
+        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
+        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int pix;
+            if (p.amode == 3) {
+                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
+            } else {
+                pix = a_pix[j] + dpix;
+            }
+            ra[j] = *reinterpret_cast<const half8_t*>(src + (long)pix * Cs + cs + lchunk * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) rb[j] = *reinterpret_cast<const half8_t*>(b_ptr[j] + ((long)kt << 6));
+    };
+    // DMA variant: same addresses, destination = wave-uniform LDS base (+ lane*16 added by hardware)
+    const int wave_row0 = __builtin_amdgcn_readfirstlane(wid) * 8;
+    auto dma_tile = [&](int kt, int stage) {
+        const int tap = kt / tiles_per_tap;
+        const int cc = (kt - tap * tiles_per_tap) << 6;
+        const half_t* src; int cs, Cs;
+        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        int dy = 0, dx = 0;
+        if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        int dpix = 0;
+        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
+        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) {
+            int pix;
+            if (p.amode == 3) {
+                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
+            } else {
+                pix = a_pix[j] + dpix;
+            }
+            const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(As + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            const half_t* g = b_ptr[j] + ((long)kt << 6);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(Bs + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int j = 0; j < A_CH; ++j) *reinterpret_cast<half8_t*>(As + st_off[j]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) *reinterpret_cast<half8_t*>(Bs + st_off[j]) = rb[j];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    // fragment read offsets: row = base + (lane&31), logical chunk = ks*2 + (lane>>5)
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int fsw = (frow >> 1) & 7;
+    const int a_rd = (wm * WTM + frow) * 128;
+    const int b_rd = (wn * WTN + frow) * 128;
+
+    if constexpr (GLDS) {
+        dma_tile(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) {
+            if constexpr (GLDS) dma_tile(kt + 1, cur ^ 1); else load_tile(kt + 1);
+        }
+        const char* As = smem + cur * STAGE_BYTES;
+        const char* Bs = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+            half8_t xa[MT], wb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+        if constexpr (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
+        } else {
+            if (kt + 1 < kt_end) store_tile(cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+    const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+    if (is_tail) {
+        // fp32 partial, register order, coalesced: ws[((block * REGS + r) * NTHR) + tid]
+        float* ws = p.ws + (long)(bid - p.n_main) * (MT * NT * 16) * NTHR + tid;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[(long)((i * NT + j) * 16 + r) * NTHR] = acc[i][j][r];
+        return;
+    }
+    igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
+}
+
+// Finishes the K-split tail tiles: sums the ksplit fp32 partials of a tile (same lane/register
+// geometry as the producing kernel) and runs the shared epilogue.
+template <int WM, int WN, int WTM, int WTN>
+__global__ void __launch_bounds__(64 * WM * WN)
+igemm_reduce_kernel(const IGemmArgs p) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int wg = p.n_main + blockIdx.x;
+    const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid - wm * WN;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = 0.f;
+                for (int sidx = 0; sidx < p.ksplit; ++sidx)
+                    v += p.ws[((long)(blockIdx.x * p.ksplit + sidx) * (MT * NT * 16) + (i * NT + j) * 16 + r) * NTHR + tid];
+                acc[i][j][r] = v;
+            }
+    igemm_epilogue<MT, NT>(p, acc, tile_m * BM + wm * WTM, tile_n * BN + wn * WTN, lane);
+}
+
+
+// ---- launch + tail scheduling ------------------------------------------------------------------
+static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
+constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
+static int g_tail_split = 0;                        // 1 = K-split the last, partially filled round (measured: not a win yet -> off)
+
+template <int WM, int WN, int WTM, int WTN, bool GLDS>
+int launch_cfg(const IGemmArgs& a_in, hipStream_t stream) {
+    constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
     constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
+    constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
     auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS>;
     if (!attr_set) {
@@ -339,8 +403,36 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    const int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), smem, stream, a);
+    IGemmArgs a = a_in;
+    const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
+    const int KT = a.K >> 6;
+    a.n_main = T; a.ksplit = 1; a.ws = nullptr;
+    const int rem = T % slots;
+    if (g_tail_split && (WTM == 64 && WTN == 64) && rem > 0 && rem < (slots * 3) / 4 && KT >= 12) {
+        // time of the last round in units of one whole-tile duration (~1 us per k-tile per block):
+        // unsplit = 1.0;  split S ways = ceil(rem*S/slots)/S + partial write/read traffic + 2 launches
+        const double t_tile_us = KT * 1.0;
+        double best = 0.88; int bestS = 1;
+        const int cand[6] = {2, 3, 4, 6, 8, 12};
+        for (int c = 0; c < 6; ++c) {
+            const int S = cand[c];
+            if (KT / S < 6 || (long)rem * S > WS_MAX_PARTS) continue;
+            const double rounds = (double)cdiv((long)rem * S, slots) / S;
+            const double traffic_us = (double)rem * S * (BM * BN * 4.0) * 2.0 / 3.0e6;     // write + read at ~3 TB/s
+            const double cost = rounds + (traffic_us + 4.0) / t_tile_us;
+            if (cost < best) { best = cost; bestS = S; }
+        }
+        if (bestS > 1) {
+            if (!g_ws) {
+                if (hipMalloc((void**)&g_ws, (size_t)WS_MAX_PARTS * 64 * 1024) != hipSuccess) { g_ws = nullptr; bestS = 1; }
+            }
+            if (bestS > 1) { a.n_main = T - rem; a.ksplit = bestS; a.ws = g_ws; }
+        }
+    }
+    const int n_tail = T - a.n_main;
+    hipLaunchKernelGGL(kern, dim3(a.n_main + n_tail * a.ksplit), dim3(NTHR), smem, stream, a);
+    if (n_tail > 0)
+        hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail), dim3(NTHR), 0, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -353,6 +445,7 @@ static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
 extern "C" void cfgpp_igemm_set_staging(int glds) { g_staging = glds ? 1 : 0; }
+extern "C" void cfgpp_igemm_set_tail_split(int on) { g_tail_split = on ? 1 : 0; }
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
     const int Cin = a.C0 + a.C1;
@@ -371,9 +464,11 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const long t256x64 = (long)cdiv(a.M, 256) * cdiv(a.N, 64);
         const bool n_odd64 = (a.N % 128) != 0;
+        const int KT = a.K >> 6;
         if (t128 >= 256 && !n_odd64) cfg = 1;
         else if (t256x64 >= 256 && (n_odd64 || a.N <= 64)) cfg = 2;
         else if (t128 >= 200) cfg = 1;
+        else if (g_tail_split && KT >= 24 && t128 >= 16) cfg = n_odd64 ? 2 : 1;   // few tiles, long K: K-split them
         else cfg = 3;
         if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
     }

@@ -154,6 +154,46 @@ def t_conv1(N=2, C0=128, C1=64, Cout=64, Hh=9, Ww=7):
     return H.err_stats(H.from_pn(got), ref)
 
 
+@case("igemm_tail_split")
+def t_tail():
+    """K-split tail path (few tiles, long K): conv3x3 + residual, GEGLU and heads epilogues through
+    igemm_reduce_kernel; must agree with the unsplit path to fp32-summation-order noise."""
+    out = {}
+    x = rnd(2, 128, 20, 16, seed=60)
+    w = rnd(192, 128, 3, 3, scale=(9 * 128) ** -0.5, seed=61)
+    b = rnd(192, scale=0.1, seed=62)
+    res = rnd(2, 192, 20, 16, seed=63)
+    ref = F.conv2d(x, w, b, padding=1) + res
+    for on in (1, 0):
+        H.lib().cfgpp_igemm_set_tail_split(on)
+        for c in (1, 2):
+            H.lib().cfgpp_igemm_force_config(c)
+            got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 20, 16, 1, None, 0, H.to_pn(res))
+            out[f"conv_tail{on}_cfg{c}"] = H.err_stats(H.from_pn(got), ref)
+    H.lib().cfgpp_igemm_set_tail_split(1)
+    a = rnd(300, 1024, seed=64)
+    wg = rnd(8 * 64, 1024, scale=1024 ** -0.5, seed=65)
+    bg = rnd(8 * 64, scale=0.1, seed=66)
+    h = a @ wg.t() + bg
+    v, g = h.chunk(2, dim=-1)
+    wp, bp = H.pack_geglu(wg, bg)
+    for c in (1, 2):
+        H.lib().cfgpp_igemm_force_config(c)
+        out[f"geglu_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1), v * F.gelu(g))
+    H.lib().cfgpp_igemm_force_config(1)
+    B, tokens, C, nheads = 2, 160, 128, 2
+    a2 = rnd(B * tokens, 1024, seed=67)
+    w2 = rnd(3 * C, 1024, scale=1024 ** -0.5, seed=68)
+    qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
+    hq, hk, hvt = H.heads_project(a2.to(H.DEV, torch.float16), w2.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
+    y = (a2 @ w2.t()).reshape(B, tokens, 3, nheads, C // nheads)
+    out["heads_q"] = H.err_stats(hq[:, :tokens, :C // nheads].reshape(B, nheads, tokens, -1), y[:, :, 0].permute(0, 2, 1, 3))
+    out["heads_vt"] = H.err_stats(hvt[:, :C // nheads, :tokens].reshape(B, nheads, -1, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+    H.lib().cfgpp_igemm_force_config(0)
+    H.lib().cfgpp_igemm_set_tail_split(0)
+    return out
+
+
 @case("groupnorm")
 def t_gn():
     out = {}
@@ -388,7 +428,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     print("[diag] device:", torch.cuda.get_device_name(0), flush=True)
-    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_gn(); t_ln(); t_attn(); t_heads()
+    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_tail(); t_gn(); t_ln(); t_attn(); t_heads()
     t_cio(); t_small(); t_step()
     t_unet_tiny_sd(); t_unet_tiny_xl()
     if not args.quick:

@@ -67,6 +67,10 @@ def test_conv1x1_two_concatenated_sources(diag):
     _check(diag, diag.t_conv1, "conv1x1_two_sources")
 
 
+def test_igemm_ksplit_tail_path(diag):
+    _check(diag, diag.t_tail, "igemm_tail_split")
+
+
 def test_groupnorm_silu_concat(diag):
     r = _check(diag, diag.t_gn, "groupnorm")
     assert all(v.get("halo_zero", True) for v in r.values())
