@@ -87,21 +87,30 @@ def prompts_for(lo, hi):
 NULL = "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,"
 
 
-def cpu_baseline(kind, name, cfg, nfe, lam, img, conds):
-    """The CPU restatement (oracle/) of the same path on the host cores: a bounded sample
-    (a few UNet + step iterations of ONE chain and one VAE decode), extrapolated."""
+def cpu_baseline_child(cfg_name, name, nfe, lam, img):
+    """Runs in a child process (so the parent can bound it): the CPU restatement (oracle/) of the same
+    path on the host cores - a bounded sample (UNet batch-2 + step iterations of ONE chain, then one VAE
+    decode), printed as JSON lines as soon as each part is measured."""
     from cfgpp_amd.schedule import SchedulerTables
+    from cfgpp_amd.unet_config import CONFIGS
     from cfgpp_amd.vae import TorchVAE
     from cfgpp_amd.weights import synth_state_dict
     from oracle import sampler as O
     from oracle.unet_ref import UNetRef
+    cfg = CONFIGS[cfg_name]
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)                 # beyond ~64 threads torch-CPU conv/GEMM stops scaling on this host
+    torch.set_num_threads(threads)
     net = UNetRef(cfg, synth_state_dict(cfg, 0))
     tb = SchedulerTables(nfe)
     hw = img // 8
-    z = torch.randn(1, 4, hw, hw)
-    ehs, ack = conds
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 4, hw, hw, generator=g)
+    ehs = torch.randn(2, 77, cfg.cross_attention_dim, generator=g) * 0.5
+    ack = None
+    if cfg.addition_embed:
+        ack = {"text_embeds": torch.randn(2, cfg.addition_pooled_dim, generator=g) * 0.5,
+               "time_ids": torch.tensor([[img, img, 0, 0, img, img]] * 2, dtype=torch.float32)}
 
     def unet(zz, t):
         eps = net(torch.cat([zz, zz]), float(t), ehs, ack)["sample"].half()
@@ -115,15 +124,34 @@ def cpu_baseline(kind, name, cfg, nfe, lam, img, conds):
         eu, ec = unet(zt, t)
         _, zt = O.ddim_step(zt, eu, ec, lam, None, None, False, True, sqrt4=tb.ddim_sqrt_coeffs(t))
     s_per_iter = (time.time() - t0) / n_iter
+    n_unet = nfe * (2 if "inversion" in name else 1)
+    out = {"value": round(1.0 / (n_unet * s_per_iter), 6), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"{n_iter} UNet(batch 2)+fused-step iterations of one chain at {hw}x{hw} timed ({s_per_iter:.2f} s/iter), "
+                     f"extrapolated to {n_unet} iterations; VAE decode not yet included"}
+    print(json.dumps(out), flush=True)
     vae = TorchVAE(cfg.vae_scale, device="cpu", dtype=torch.float32)
     t0 = time.time()
     vae.decode(zt)
     dec_s = time.time() - t0
-    n_unet = nfe * (2 if "inversion" in name else 1)
-    total = n_unet * s_per_iter + dec_s
-    return {"value": round(1.0 / total, 6), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_iter} UNet(batch 2)+step iterations of one chain at {hw}x{hw} and one VAE decode, "
-                      f"timed ({s_per_iter:.2f} s/iter, decode {dec_s:.2f} s) and extrapolated to {n_unet} iterations"}
+    out["value"] = round(1.0 / (n_unet * s_per_iter + dec_s), 6)
+    out["sample"] = (f"{n_iter} UNet(batch 2)+fused-step iterations of one chain at {hw}x{hw} ({s_per_iter:.2f} s/iter) and one VAE "
+                     f"decode ({dec_s:.2f} s) timed on {threads} threads, extrapolated to {n_unet} iterations + decode")
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(cfg_name, name, nfe, lam, img, limit_s=240):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", cfg_name, name, str(nfe), str(lam), str(img)]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+    try:
+        outp, _ = p.communicate(timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        outp, _ = p.communicate()
+    lines = [ln for ln in (outp or "").strip().splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": f"cpu baseline produced nothing within {limit_s}s"}
+    return json.loads(lines[-1])
 
 
 def main():
@@ -228,20 +256,18 @@ def main():
                               "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in agg.items()},
                               "attention_TFLOPs": round(agg["attention"]["flops"] / (agg["attention"]["ms"] * 1e-3) / 1e12, 1)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if kind == "sd":
-            conds = (torch.cat([cond[0], cond[1][:1]]).float().cpu(), None)
-        else:
-            ack = {"text_embeds": torch.cat([cond[2], cond[3][:1]]).float().cpu(),
-                   "time_ids": torch.tensor([[img, img, 0, 0, img, img]] * 2, dtype=torch.float32)}
-            conds = (torch.cat([cond[0], cond[1][:1]]).float().cpu(), ack)
-        log("cpu baseline ...")
+        log("cpu baseline (child process, bounded) ...")
         try:
-            result["cpu_baseline"] = cpu_baseline(kind, name, cfg, nfe, lam, img, conds)
+            result["cpu_baseline"] = cpu_baseline(cfg_name, name, nfe, lam, img)
         except Exception as e:  # noqa: BLE001
             result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-child":
+        cpu_baseline_child(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
+    else:
+        main()

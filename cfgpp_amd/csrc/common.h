@@ -51,4 +51,14 @@ struct RowMap {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-GELU x*Phi(x) with erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16
+// output resolution): 1 rcp + 1 exp2 + a degree-5 Horner instead of libm erff (~3x fewer VALU ops in the
+// GEGLU epilogue, which evaluates it 4C times per token).
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erfc_ax = poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float cdf = x >= 0.f ? 1.0f - 0.5f * erfc_ax : 0.5f * erfc_ax;
+    return x * cdf;
+}

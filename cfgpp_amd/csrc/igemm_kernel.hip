@@ -140,7 +140,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 // GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
-template <int WM, int WN, int WTM, int WTN, bool GLDS>
+// AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
     constexpr int NTHR = 64 * WM * WN;
@@ -188,9 +189,9 @@ igemm_kernel(const IGemmArgs p) {
     for (int j = 0; j < A_CH; ++j) {
         int m = m0 + lrow + j * RSTEP;
         m = m < p.M ? m : p.M - 1;
-        if (p.amode == 0) a_pix[j] = m;
-        else if (p.amode == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
-        else if (p.amode == 2) {
+        if constexpr (AMODE == 0) a_pix[j] = m;
+        else if constexpr (AMODE == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
+        else if constexpr (AMODE == 2) {
             const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
             a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1) * (2 * p.W + 2) + 2 * x + 1;
         } else {
@@ -224,17 +225,18 @@ igemm_kernel(const IGemmArgs p) {
     auto load_tile = [&](int kt) {
         const int tap = kt / tiles_per_tap;
         const int cc = (kt - tap * tiles_per_tap) << 6;
-        const half_t* src; int cs, Cs;
-        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        const bool s0 = cc < p.C0;
+        const half_t* src = s0 ? p.a0 : p.a1;
+        const int cs = s0 ? cc : cc - p.C0, Cs = s0 ? p.C0 : p.C1;
         int dy = 0, dx = 0;
         if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
         int dpix = 0;
-        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
-        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+        if constexpr (AMODE == 1) dpix = dy * (p.W + 2) + dx;
+        else if constexpr (AMODE == 2) dpix = dy * (2 * p.W + 2) + dx;
 #pragma unroll
         for (int j = 0; j < A_CH; ++j) {
             int pix;
-            if (p.amode == 3) {
+            if constexpr (AMODE == 3) {
                 const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
                 const int Hs = p.H >> 1, Ws = p.W >> 1;
                 pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
@@ -251,19 +253,20 @@ igemm_kernel(const IGemmArgs p) {
     auto dma_tile = [&](int kt, int stage) {
         const int tap = kt / tiles_per_tap;
         const int cc = (kt - tap * tiles_per_tap) << 6;
-        const half_t* src; int cs, Cs;
-        if (cc < p.C0) { src = p.a0; cs = cc; Cs = p.C0; } else { src = p.a1; cs = cc - p.C0; Cs = p.C1; }
+        const bool s0 = cc < p.C0;
+        const half_t* src = s0 ? p.a0 : p.a1;
+        const int cs = s0 ? cc : cc - p.C0, Cs = s0 ? p.C0 : p.C1;
         int dy = 0, dx = 0;
         if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
         int dpix = 0;
-        if (p.amode == 1) dpix = dy * (p.W + 2) + dx;
-        else if (p.amode == 2) dpix = dy * (2 * p.W + 2) + dx;
+        if constexpr (AMODE == 1) dpix = dy * (p.W + 2) + dx;
+        else if constexpr (AMODE == 2) dpix = dy * (2 * p.W + 2) + dx;
         char* As = smem + stage * STAGE_BYTES;
         char* Bs = As + BM * 128;
 #pragma unroll
         for (int j = 0; j < A_CH; ++j) {
             int pix;
-            if (p.amode == 3) {
+            if constexpr (AMODE == 3) {
                 const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
                 const int Hs = p.H >> 1, Ws = p.W >> 1;
                 pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
@@ -319,19 +322,29 @@ igemm_kernel(const IGemmArgs p) {
         }
         const char* As = smem + cur * STAGE_BYTES;
         const char* Bs = As + BM * 128;
+        // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+        half8_t xa[2][MT], wb[2][NT];
+        {
+            const int coff = ((0 | fhi) ^ fsw) << 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
-            half8_t xa[MT], wb[NT];
+            if (ks < 3) {
+                const int coff = ((((ks + 1) << 1) | fhi) ^ fsw) << 4;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+                for (int i = 0; i < MT; ++i) xa[(ks + 1) & 1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+                for (int j = 0; j < NT; ++j) wb[(ks + 1) & 1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][j], xa[ks & 1][i], acc[i][j], 0, 0, 0);
         }
         if constexpr (GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
@@ -388,16 +401,18 @@ igemm_reduce_kernel(const IGemmArgs p) {
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
+static int g_dbg = 0;
+extern "C" void cfgpp_igemm_set_debug(int flags) { g_dbg = flags; }   // ablation hooks are compiled out of the product kernel
 static int g_tail_split = 0;                        // 1 = K-split the last, partially filled round (measured: not a win yet -> off)
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS>
-int launch_cfg(const IGemmArgs& a_in, hipStream_t stream) {
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE>
+int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
     constexpr int smem = 2 * (BM + BN) * 128;
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -406,7 +421,7 @@ int launch_cfg(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
-    a.n_main = T; a.ksplit = 1; a.ws = nullptr;
+    a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.dbg = g_dbg;
     const int rem = T % slots;
     if (g_tail_split && (WTM == 64 && WTN == 64) && rem > 0 && rem < (slots * 3) / 4 && KT >= 12) {
         // time of the last round in units of one whole-tile duration (~1 us per k-tile per block):
@@ -435,6 +450,17 @@ int launch_cfg(const IGemmArgs& a_in, hipStream_t stream) {
         hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail), dim3(NTHR), 0, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+template <int WM, int WN, int WTM, int WTN, bool GLDS>
+int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
+    switch (a.amode) {
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0>(a, stream);
+        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1>(a, stream);
+        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2>(a, stream);
+        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3>(a, stream);
+        default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
+    }
 }
 
 }  // namespace
