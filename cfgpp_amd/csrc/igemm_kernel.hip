@@ -369,8 +369,10 @@ igemm_kernel(const IGemmArgs p) {
     igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
 }
 
-// Finishes the K-split tail tiles: sums the ksplit fp32 partials of a tile (same lane/register
-// geometry as the producing kernel) and runs the shared epilogue.
+// Finishes the K-split tiles: block (t, ij) sums the ksplit fp32 partials of ONE 32x32 MFMA sub-tile
+// per wave (same lane/register geometry as the producing kernel) and runs the shared epilogue on it.
+// grid = (tiles, MT*NT): 4x more blocks than tiles and 16 x ksplit independent loads per thread, so the
+// pass is bandwidth- rather than latency-bound.
 template <int WM, int WN, int WTM, int WTN>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_reduce_kernel(const IGemmArgs p) {
@@ -379,31 +381,36 @@ igemm_reduce_kernel(const IGemmArgs p) {
     constexpr int MT = WTM / 32, NT = WTN / 32;
     const int ntn = (p.N + BN - 1) / BN;
     const int wg = p.n_main + blockIdx.x;
+    const int ij = blockIdx.y, i = ij / NT, j = ij - i * NT;
     const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid - wm * WN;
-    f32x16 acc[MT][NT];
+    const float* base = p.ws + ((long)blockIdx.x * p.ksplit * (MT * NT * 16) + (long)ij * 16) * NTHR + tid;
+    const long sstride = (long)(MT * NT * 16) * NTHR;
+    f32x16 acc[1][1];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    int sidx = 0;
+    for (; sidx + 2 <= p.ksplit; sidx += 2) {
+        float v0[16], v1[16];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int r = 0; r < 16; ++r) { v0[r] = base[sidx * sstride + (long)r * NTHR]; v1[r] = base[(sidx + 1) * sstride + (long)r * NTHR]; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = 0.f;
-                for (int sidx = 0; sidx < p.ksplit; ++sidx)
-                    v += p.ws[((long)(blockIdx.x * p.ksplit + sidx) * (MT * NT * 16) + (i * NT + j) * 16 + r) * NTHR + tid];
-                acc[i][j][r] = v;
-            }
-    igemm_epilogue<MT, NT>(p, acc, tile_m * BM + wm * WTM, tile_n * BN + wn * WTN, lane);
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += v0[r] + v1[r];
+    }
+    if (sidx < p.ksplit) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += base[sidx * sstride + (long)r * NTHR];
+    }
+    igemm_epilogue<1, 1>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane);
 }
-
 
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
 static int g_dbg = 0;
 extern "C" void cfgpp_igemm_set_debug(int flags) { g_dbg = flags; }   // ablation hooks are compiled out of the product kernel
-static int g_tail_split = 0;                        // 1 = K-split the last, partially filled round (measured: not a win yet -> off)
+static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
 
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
@@ -422,32 +429,22 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
     a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.dbg = g_dbg;
-    const int rem = T % slots;
-    if (g_tail_split && (WTM == 64 && WTN == 64) && rem > 0 && rem < (slots * 3) / 4 && KT >= 12) {
-        // time of the last round in units of one whole-tile duration (~1 us per k-tile per block):
-        // unsplit = 1.0;  split S ways = ceil(rem*S/slots)/S + partial write/read traffic + 2 launches
-        const double t_tile_us = KT * 1.0;
-        double best = 0.88; int bestS = 1;
-        const int cand[6] = {2, 3, 4, 6, 8, 12};
-        for (int c = 0; c < 6; ++c) {
-            const int S = cand[c];
-            if (KT / S < 6 || (long)rem * S > WS_MAX_PARTS) continue;
-            const double rounds = (double)cdiv((long)rem * S, slots) / S;
-            const double traffic_us = (double)rem * S * (BM * BN * 4.0) * 2.0 / 3.0e6;     // write + read at ~3 TB/s
-            const double cost = rounds + (traffic_us + 4.0) / t_tile_us;
-            if (cost < best) { best = cost; bestS = S; }
-        }
-        if (bestS > 1) {
-            if (!g_ws) {
-                if (hipMalloc((void**)&g_ws, (size_t)WS_MAX_PARTS * 64 * 1024) != hipSuccess) { g_ws = nullptr; bestS = 1; }
-            }
-            if (bestS > 1) { a.n_main = T - rem; a.ksplit = bestS; a.ws = g_ws; }
+    // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
+    // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
+    // finishes them.  S is chosen so that T*S fills the resident slots once or twice.
+    if (g_tail_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
+        int S = (slots + T - 1) / T;                       // one full round
+        if (KT / S < 12) S = KT / 12;
+        if (S > 16) S = 16;
+        if (S >= 2 && (long)T * S <= WS_MAX_PARTS) {
+            if (!g_ws && hipMalloc((void**)&g_ws, (size_t)WS_MAX_PARTS * 64 * 1024) != hipSuccess) g_ws = nullptr;
+            if (g_ws) { a.n_main = 0; a.ksplit = S; a.ws = g_ws; }
         }
     }
     const int n_tail = T - a.n_main;
     hipLaunchKernelGGL(kern, dim3(a.n_main + n_tail * a.ksplit), dim3(NTHR), smem, stream, a);
     if (n_tail > 0)
-        hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail), dim3(NTHR), 0, stream, a);
+        hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail, (WTM / 32) * (WTN / 32)), dim3(NTHR), 0, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -494,7 +491,7 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         if (t128 >= 256 && !n_odd64) cfg = 1;
         else if (t256x64 >= 256 && (n_odd64 || a.N <= 64)) cfg = 2;
         else if (t128 >= 200) cfg = 1;
-        else if (g_tail_split && KT >= 24 && t128 >= 16) cfg = n_odd64 ? 2 : 1;   // few tiles, long K: K-split them
+        else if (g_tail_split && KT >= 32 && t128 >= 8 && a.epi == EPI_STORE) cfg = 1;   // few tiles, long K: K-split them
         else cfg = 3;
         if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
     }

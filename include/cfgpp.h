@@ -144,7 +144,7 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
 void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64; +10 = register-staged variant */
-void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split the partially filled last round of tiles (experimental, default 0) */
+void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
 void cfgpp_igemm_set_debug(int flags);    /* benchmark ablation: bit0 skip tile loads, bit1 skip MFMA */
 void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */
 

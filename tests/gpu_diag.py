@@ -159,8 +159,8 @@ def t_tail():
     """K-split tail path (few tiles, long K): conv3x3 + residual, GEGLU and heads epilogues through
     igemm_reduce_kernel; must agree with the unsplit path to fp32-summation-order noise."""
     out = {}
-    x = rnd(2, 128, 20, 16, seed=60)
-    w = rnd(192, 128, 3, 3, scale=(9 * 128) ** -0.5, seed=61)
+    x = rnd(2, 256, 20, 16, seed=60)
+    w = rnd(192, 256, 3, 3, scale=(9 * 256) ** -0.5, seed=61)
     b = rnd(192, scale=0.1, seed=62)
     res = rnd(2, 192, 20, 16, seed=63)
     ref = F.conv2d(x, w, b, padding=1) + res
@@ -171,8 +171,8 @@ def t_tail():
             got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 20, 16, 1, None, 0, H.to_pn(res))
             out[f"conv_tail{on}_cfg{c}"] = H.err_stats(H.from_pn(got), ref)
     H.lib().cfgpp_igemm_set_tail_split(1)
-    a = rnd(300, 1024, seed=64)
-    wg = rnd(8 * 64, 1024, scale=1024 ** -0.5, seed=65)
+    a = rnd(300, 2048, seed=64)
+    wg = rnd(8 * 64, 2048, scale=2048 ** -0.5, seed=65)
     bg = rnd(8 * 64, scale=0.1, seed=66)
     h = a @ wg.t() + bg
     v, g = h.chunk(2, dim=-1)
@@ -182,15 +182,19 @@ def t_tail():
         out[f"geglu_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1), v * F.gelu(g))
     H.lib().cfgpp_igemm_force_config(1)
     B, tokens, C, nheads = 2, 160, 128, 2
-    a2 = rnd(B * tokens, 1024, seed=67)
-    w2 = rnd(3 * C, 1024, scale=1024 ** -0.5, seed=68)
+    a2 = rnd(B * tokens, 2048, seed=67)
+    w2 = rnd(3 * C, 2048, scale=2048 ** -0.5, seed=68)
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     hq, hk, hvt = H.heads_project(a2.to(H.DEV, torch.float16), w2.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
     y = (a2 @ w2.t()).reshape(B, tokens, 3, nheads, C // nheads)
     out["heads_q"] = H.err_stats(hq[:, :tokens, :C // nheads].reshape(B, nheads, tokens, -1), y[:, :, 0].permute(0, 2, 1, 3))
     out["heads_vt"] = H.err_stats(hvt[:, :C // nheads, :tokens].reshape(B, nheads, -1, tokens), y[:, :, 2].permute(0, 2, 3, 1))
     H.lib().cfgpp_igemm_force_config(0)
-    H.lib().cfgpp_igemm_set_tail_split(0)
+    H.lib().cfgpp_igemm_set_tail_split(1)
+    # plain linear through the split path: M=256, N=256, K=4096 (KT=64)
+    a3, w3, b3, r3 = rnd(256, 4096, seed=70), rnd(256, 4096, scale=1 / 64, seed=71), rnd(256, scale=0.1, seed=72), rnd(256, 256, seed=73)
+    out["linear_split"] = H.err_stats(H.linear(a3.to(H.DEV, torch.float16), w3.to(H.DEV, torch.float16), b3.to(H.DEV), r3.to(H.DEV, torch.float16)),
+                                      a3 @ w3.t() + b3 + r3)
     return out
 
 
