@@ -43,6 +43,8 @@ PROTOTYPES = {
     "cfgpp_step_ddim": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
     "cfgpp_kdiff_input": (_I, [_P, _P, _F, _I, _L, _P]),
     "cfgpp_step_kdiff": (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_float), _I, _I, _I, _I, _L, _P]),
+    "cfgpp_kdiff_denoise": (_I, [_P, _P, _P, _F, _F, _P, _P, _L, _P]),
+    "cfgpp_lincomb": (_I, [_P, _P, _P, _P, _F, _F, _I, _L, _P]),
     "cfgpp_unet_create": (_P, [C.POINTER(UNetConfigC), _I]),
     "cfgpp_unet_destroy": (None, [_P]),
     "cfgpp_unet_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),

@@ -140,6 +140,38 @@ kdiff_step_kernel(half_t* __restrict__ x, half_t* __restrict__ den_out, half_t* 
     }
 }
 
+// ---- building blocks of the 2-stage / ancestral k-diffusion samplers (fp16 latents) --------------
+// den = x - h(eps_hat*sigma), uden = x - h(eps_uc*sigma)           (latent_diffusion.py:235-241)
+__global__ void __launch_bounds__(256)
+kdiff_denoise_kernel(const half_t* __restrict__ x, const half_t* __restrict__ eps_uc, const half_t* __restrict__ eps_c,
+                     float lam, float sigma, half_t* __restrict__ den, half_t* __restrict__ uden, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float xv = (float)x[i], uc = (float)eps_uc[i], cc = (float)eps_c[i];
+        const float hat = cfg_mix_h(uc, cc, lam);
+        den[i] = (half_t)__fsub_rn(xv, h_round(__fmul_rn(hat, sigma)));
+        uden[i] = (half_t)__fsub_rn(xv, h_round(__fmul_rn(uc, sigma)));
+    }
+}
+// mode 0: out = h( h(x*a) - h(y*b) )                 x_2 / x of DPM-Solver++(2S)   (latent_diffusion.py:428,435,804)
+// mode 1: out = h( h(y - h(z*b)) + h(x*a) )          CFG++ 2S final update          (latent_diffusion.py:811)
+// mode 2: out = h( x + h(y*a) )                      ancestral noise                (latent_diffusion.py:379,438)
+__global__ void __launch_bounds__(256)
+lincomb_kernel(half_t* __restrict__ out, const half_t* __restrict__ x, const half_t* __restrict__ y,
+               const half_t* __restrict__ z, float a, float b, int mode, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float xv = (float)x[i], yv = (float)y[i];
+        float r;
+        if (mode == 0) r = __fsub_rn(h_round(__fmul_rn(xv, a)), h_round(__fmul_rn(yv, b)));
+        else if (mode == 1) r = __fadd_rn(h_round(__fsub_rn(yv, h_round(__fmul_rn((float)z[i], b)))), h_round(__fmul_rn(xv, a)));
+        else r = __fadd_rn(xv, h_round(__fmul_rn(yv, a)));
+        out[i] = (half_t)r;
+    }
+}
+
 inline int grid_for(long items) {
     long g = (items + 255) / 256;
     if (g > 2048) g = 2048;
@@ -187,6 +219,23 @@ int cfgpp_step_kdiff(void* x, void* den_out, void* old, const void* eps_uc, cons
     hipLaunchKernelGGL(kdiff_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                        (half_t*)x, (half_t*)den_out, (half_t*)old, (const half_t*)eps_uc, (const half_t*)eps_c,
                        k, variant, xl_form, euler_branch, write_old, n);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_kdiff_denoise(const void* x, const void* eps_uc, const void* eps_c, float lam, float sigma,
+                        void* den, void* uden, long n, void* stream) {
+    CFGPP_REQUIRE(n > 0 && x && eps_uc && eps_c && den && uden, "cfgpp_kdiff_denoise: bad args");
+    hipLaunchKernelGGL(kdiff_denoise_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (const half_t*)eps_uc, (const half_t*)eps_c, lam, sigma, (half_t*)den, (half_t*)uden, n);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_lincomb(void* out, const void* x, const void* y, const void* z, float a, float b, int mode, long n, void* stream) {
+    CFGPP_REQUIRE(n > 0 && out && x && y && mode >= 0 && mode <= 2 && (mode != 1 || z), "cfgpp_lincomb: bad args");
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (half_t*)out, (const half_t*)x,
+                       (const half_t*)y, (const half_t*)z, a, b, mode, n);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -81,6 +81,26 @@ def step_kdiff(x: torch.Tensor, den_out: torch.Tensor, old: Optional[torch.Tenso
                                x.numel(), _stream_ptr()), "cfgpp_step_kdiff")
 
 
+def kdiff_denoise(x, eps_uc, eps_c, lam: float, sigma: float, den_out, uden_out):
+    lib = _lib.load()
+    for n, t in (("x", x), ("eps_uc", eps_uc), ("eps_c", eps_c), ("den_out", den_out), ("uden_out", uden_out)):
+        _require_cuda(t, n)
+        if t.dtype != torch.float16:
+            raise CfgppError(f"kdiff_denoise: {n} must be fp16")
+    check(lib.cfgpp_kdiff_denoise(x.data_ptr(), eps_uc.data_ptr(), eps_c.data_ptr(), float(lam), float(sigma),
+                                  den_out.data_ptr(), uden_out.data_ptr(), x.numel(), _stream_ptr()), "cfgpp_kdiff_denoise")
+
+
+def lincomb(out, x, y, z, a: float, b: float, mode: int):
+    lib = _lib.load()
+    for n, t in (("out", out), ("x", x), ("y", y)) + ((("z", z),) if z is not None else ()):
+        _require_cuda(t, n)
+        if t.dtype != torch.float16:
+            raise CfgppError(f"lincomb: {n} must be fp16")
+    check(lib.cfgpp_lincomb(out.data_ptr(), x.data_ptr(), y.data_ptr(), _ptr(z), float(a), float(b), int(mode), x.numel(),
+                            _stream_ptr()), "cfgpp_lincomb")
+
+
 # ----------------------------------------------------------------------------
 # UNet engine
 # ----------------------------------------------------------------------------

@@ -68,6 +68,12 @@ class HipEngine:
     step_ddim = staticmethod(E.step_ddim)
     kdiff_input = staticmethod(E.kdiff_input)
     step_kdiff = staticmethod(E.step_kdiff)
+    kdiff_denoise = staticmethod(E.kdiff_denoise)
+    lincomb = staticmethod(E.lincomb)
+
+    def randn_like(self, x):
+        """ancestral noise: device RNG, like the reference's torch.randn_like on the GPU"""
+        return torch.randn_like(x)
 
     def flops_per_forward(self, rows: int) -> float:
         return self.unet.flops(rows)

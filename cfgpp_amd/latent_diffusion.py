@@ -294,6 +294,60 @@ class StableDiffusion:
         return den, x
 
 
+    # ------------------------------------------------------------------ ancestral k-diffusion loops
+    def _ancestral_loop(self, uc, c, cfg_guidance, cfgpp: bool, two_stage: bool, callback_fn=None, seeds=None):
+        """Euler-ancestral (latent_diffusion.py:349-390 / 726-766) and DPM-Solver++(2S)-ancestral
+        (:393-451 / 769-827; two UNet calls per step) on Karras sigmas, fp16 latent.  The injected noise
+        is drawn with ``engine.randn_like`` (device RNG on the GPU, like the reference's torch.randn_like)."""
+        B = self._batch_of(c, None)
+        lam = cfg_guidance
+        sigmas = self.tables.karras_sigmas()
+        x = self.initialize_latent(method="random_kdiffusion", latent_dim=(B, self.cfg.in_channels) + self.latent_hw,
+                                   sigmas=sigmas, seeds=seeds).to(torch.float16).contiguous()
+        xc, den, uden = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        x2, den2, uden2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        variant = 1 if cfgpp else 0
+        sem = self.scalar_semantics
+        t_fn = lambda sg: sg.log().neg()       # noqa: E731
+        sigma_fn = lambda tt: tt.neg().exp()   # noqa: E731
+        first = lambda sc: K._first(K._s(sc), True, sem)   # noqa: E731  scalar written first in `s * fp16`
+        n = len(self.scheduler.timesteps)
+        for i in _progress(range(n), "SD"):
+            sigma = sigmas[i]
+            new_t = self.timestep(sigma)
+            sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1])
+            self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma), 0)
+            noise_uc, noise_c = self.predict_noise(xc, new_t, uc, c)
+            if (not two_stage) or float(sigma_down) == 0.0:
+                # Euler step down to sigma_down: x = den + ((x - d_from)/sigma) * sigma_down
+                coef = [float(lam), float(sigma), 0.0, float(sigma.item()), float(sigma_down), 0.0, 0.0, 1.0, 0.0]
+                self.engine.step_kdiff(x, den, None, noise_uc, noise_c, coef, variant, False, True, False)
+            else:
+                self.engine.kdiff_denoise(x, noise_uc, noise_c, lam, float(sigma), den, uden)
+                t, t_next = t_fn(sigmas[i]), t_fn(K._s(sigma_down))
+                r = 1 / 2
+                h = t_next - t
+                s_mid = t + r * h
+                # x_2 = (sigma(s)/sigma(t)) * x - expm1(-h r) * (den | uden)
+                self.engine.lincomb(x2, x, uden if cfgpp else den, None, first(sigma_fn(s_mid) / sigma_fn(t)),
+                                    first((-h * r).expm1()), 0)
+                sigma_s = sigma_fn(s_mid)
+                t_2 = self.timestep(sigma_s)
+                self.engine.kdiff_input(x2, xc, K.kdiff_input_scale_sd(sigma_s), 0)
+                nuc2, nc2 = self.predict_noise(xc, t_2, uc, c)
+                self.engine.kdiff_denoise(x2, nuc2, nc2, lam, float(sigma_s), den2, uden2)
+                ratio_n = first(sigma_fn(t_next) / sigma_fn(t))
+                if cfgpp:   # x = den_2 - exp(-h) * uden_2 + ratio * x
+                    self.engine.lincomb(x, x, den2, uden2, ratio_n, first(torch.exp(-h)), 1)
+                else:       # x = ratio * x - expm1(-h) * den_2
+                    self.engine.lincomb(x, x, den2, None, ratio_n, first((-h).expm1()), 0)
+            if sigmas[i + 1] > 0:
+                self.engine.lincomb(x, x, self.engine.randn_like(x), None, float(sigma_up), 0.0, 2)
+            if callback_fn is not None:
+                self._run_callback(callback_fn, i, new_t, den, x)
+        return den, x
+
+
 ###########################################
 # Base version
 ###########################################
@@ -336,15 +390,22 @@ class EulerCFGSolver(StableDiffusion):
 
 @register_solver("euler_a")
 class EulerAncestralCFGSolver(StableDiffusion):
-    """Euler ancestral (reference: latent_diffusion.py:349-390) - SURVEY.md 8f row f2, not built yet."""
+    """Karras Euler + ancestral sampling (reference: latent_diffusion.py:349-390)."""
+    cfgpp, two_stage = False, False
 
-    def sample(self, *a, **k):
-        raise NotImplementedError("euler_a: ancestral samplers are scheduled after the hot path (SURVEY.md 8f-2)")
+    @torch.no_grad()
+    def sample(self, cfg_guidance, prompt=["", ""], callback_fn=None, **kwargs):
+        uc, c = self._embeds(prompt, kwargs)
+        den, x = self._ancestral_loop(uc, c, cfg_guidance, self.cfgpp, self.two_stage, callback_fn, kwargs.get("seeds"))
+        if kwargs.get("return_latents"):
+            return den, x
+        return self._finish(x if self.two_stage else den)     # Euler-a decodes `denoised`, 2S-a decodes `x`
 
 
 @register_solver("dpm++_2s_a")
 class DPMpp2sAncestralCFGSolver(EulerAncestralCFGSolver):
-    """reference: latent_diffusion.py:393-451 - SURVEY.md 8f row f2, not built yet."""
+    """DPM-Solver++(2S) ancestral, two UNet calls per step (reference: latent_diffusion.py:393-451)."""
+    cfgpp, two_stage = False, True
 
 
 @register_solver("dpm++_2m")
@@ -405,12 +466,14 @@ class EulerCFGppSolver(EulerCFGSolver):
 
 @register_solver("euler_a_cfg++")
 class EulerAncestralCFGppSolver(EulerAncestralCFGSolver):
-    """reference: latent_diffusion.py:726-766 - SURVEY.md 8f row f2, not built yet."""
+    """reference: latent_diffusion.py:726-766 (d from uncond_denoised)."""
+    cfgpp, two_stage = True, False
 
 
 @register_solver("dpm++_2s_a_cfg++")
 class DPMpp2sAncestralCFGppSolver(EulerAncestralCFGSolver):
-    """reference: latent_diffusion.py:769-827 - SURVEY.md 8f row f2, not built yet."""
+    """reference: latent_diffusion.py:769-827 (x_2 from uncond_denoised; x = D_2 - e^{-h} D_uc,2 + ratio x)."""
+    cfgpp, two_stage = True, True
 
 
 @register_solver("dpm++_2m_cfg++")

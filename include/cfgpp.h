@@ -51,6 +51,16 @@ int cfgpp_step_kdiff(void* x, void* den_out, void* old, const void* eps_uc, cons
                      const float* coef_host, int variant, int xl_form, int euler_branch, int write_old,
                      long n, void* stream);
 
+/* denoised = x - eps_hat*sigma and uncond_denoised = x - eps_uc*sigma on fp16 latents
+ * (kdiffusion_x_to_denoised, latent_diffusion.py:235-241); used by the 2-stage DPM++(2S) samplers. */
+int cfgpp_kdiff_denoise(const void* x, const void* eps_uc, const void* eps_c, float lam, float sigma,
+                        void* den, void* uden, long n, void* stream);
+/* fp16 linear combinations with torch's rounding order (out may alias x):
+ * mode 0: out = x*a - y*b            (latent_diffusion.py:428,435,804)
+ * mode 1: out = (y - z*b) + x*a      (latent_diffusion.py:811)
+ * mode 2: out = x + y*a              (ancestral noise, latent_diffusion.py:379,438,755,814) */
+int cfgpp_lincomb(void* out, const void* x, const void* y, const void* z, float a, float b, int mode, long n, void* stream);
+
 /* ---- UNet engine (replaces `self.unet(...)`) ------------------------------ */
 
 typedef struct cfgpp_unet_config {

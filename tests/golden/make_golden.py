@@ -190,6 +190,11 @@ run_sd("dpm++_2m_cfg++", "G4/sd_dpm2m_cfgpp", 20, 0.6)
 run_sd("dpm++_2m", "G4/sd_dpm2m_cfg", 10, 7.5)
 run_sd("euler_cfg++", "G4/sd_euler_cfgpp", 10, 0.6)
 run_sd("euler", "G4/sd_euler_cfg", 10, 7.5)
+# ancestral samplers: the noise comes from the global CPU generator (torch.randn_like on CPU), drawn after z_T
+run_sd("euler_a", "G4/sd_euler_a_cfg", 8, 7.5)
+run_sd("euler_a_cfg++", "G4/sd_euler_a_cfgpp", 8, 0.6)
+run_sd("dpm++_2s_a", "G4/sd_dpm2s_a_cfg", 8, 7.5)
+run_sd("dpm++_2s_a_cfg++", "G4/sd_dpm2s_a_cfgpp", 8, 0.6)
 
 # ----------------------------------------------------------------------------
 # SDXL trajectories (G2-G5)

@@ -80,6 +80,26 @@ def emulate_step_kdiff(x, den_out, old, eps_uc, eps_c, coef, variant, xl_form, e
     x.copy_(_h(xn))
 
 
+def emulate_kdiff_denoise(x, eps_uc, eps_c, lam, sigma, den_out, uden_out):
+    r = lambda t: _f(_h(t))  # noqa: E731
+    xv, uc = _f(x), _f(eps_uc)
+    hat = _f(O.cfg_mix(eps_uc, eps_c, float(lam)))
+    den_out.copy_(_h(xv - r(hat * _c(sigma))))
+    uden_out.copy_(_h(xv - r(uc * _c(sigma))))
+
+
+def emulate_lincomb(out, x, y, z, a, b, mode):
+    r = lambda t: _f(_h(t))  # noqa: E731
+    xv, yv = _f(x), _f(y)
+    if mode == 0:
+        v = r(xv * _c(a)) - r(yv * _c(b))
+    elif mode == 1:
+        v = r(yv - r(_f(z) * _c(b))) + r(xv * _c(a))
+    else:
+        v = xv + r(yv * _c(a))
+    out.copy_(_h(v))
+
+
 class MockEngine:
     """unet_fn(z_rows [2B,4,H,W], t float, ehs [2B,77,D], text_embeds|None, time_ids|None) -> eps [2B,4,H,W]"""
 
@@ -108,3 +128,8 @@ class MockEngine:
     step_ddim = staticmethod(emulate_step_ddim)
     kdiff_input = staticmethod(emulate_kdiff_input)
     step_kdiff = staticmethod(emulate_step_kdiff)
+    kdiff_denoise = staticmethod(emulate_kdiff_denoise)
+    lincomb = staticmethod(emulate_lincomb)
+
+    def randn_like(self, x):
+        return torch.randn_like(x)

@@ -279,11 +279,22 @@ def StableZ(seed):
     return torch.randn(1, 4, 8, 8, generator=g)
 
 
-def test_not_built_yet_solvers_say_so():
-    for n in ("euler_a", "dpm++_2s_a", "euler_a_cfg++", "dpm++_2s_a_cfg++"):
-        s, _ = make_sd(n, 5)
-        with pytest.raises(NotImplementedError):
-            s.sample(cfg_guidance=1.0)
+@pytest.mark.parametrize("name,tag,lam", [("euler_a", "G4/sd_euler_a_cfg", 7.5), ("euler_a_cfg++", "G4/sd_euler_a_cfgpp", 0.6),
+                                           ("dpm++_2s_a", "G4/sd_dpm2s_a_cfg", 7.5), ("dpm++_2s_a_cfg++", "G4/sd_dpm2s_a_cfgpp", 0.6)])
+def test_sd_ancestral_trajectory(golden, name, tag, lam, monkeypatch):
+    """ancestral samplers: the reference draws its noise from the global CPU generator after z_T, at 64x64;
+    replay the same draws (cropped) through the mock engine."""
+    g, meta = golden
+    s, eng = make_sd(name, 8)
+    monkeypatch.setattr(s, "_randn", lambda size, seeds=None: (torch.manual_seed(42), torch.randn(1, 4, 64, 64))[1][..., :8, :8].contiguous())
+    eng.randn_like = lambda x: torch.randn_like(torch.empty(1, 4, 64, 64, dtype=x.dtype))[..., :8, :8].contiguous()
+    rec = Rec()
+    s.sample(cfg_guidance=lam, prompt=meta[tag]["prompts"], callback_fn=rec)
+    uz = T(g[tag + "/unet_z"])
+    assert len(eng.calls) == uz.shape[0]
+    for i, c in enumerate(eng.calls):
+        assert torch.equal(c["z"], uz[i][0:1]), f"unet call {i}"
+    assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"])) and torch.equal(torch.stack(rec.zt), T(g[tag + "/zt"]))
 
 
 def test_product_path_has_no_cpu_fallback():
