@@ -230,7 +230,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
         "config": {"workload": desc, "per_gpu_batch": B, "global_batch": total, "nfe": nfe, "lambda": lam,
-                   "unet_batch_rows": rows, "includes": "UNet + fused CFG++ step x NFE, VAE decode (torch-ROCm, interim), D2H copy",
+                   "unet_batch_rows": rows, "includes": "UNet + fused CFG++ step x NFE, VAE decode (HIP kernels), D2H copy",
                    "weights": "seeded synthetic, exact diffusers shapes", "flops_per_image": flops_per_image,
                    "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
     }

@@ -55,6 +55,15 @@ PROTOTYPES = {
     "cfgpp_unet_profile": (_I, [_P, _P, _I, _I, _F, _P, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, _L]),
     "cfgpp_unet_flops": (C.c_double, [_P, _I]),
     "cfgpp_unet_device_bytes": (C.c_double, [_P]),
+    "cfgpp_vae_create": (_P, [_I, _I, _I, _F, _I]),
+    "cfgpp_vae_destroy": (None, [_P]),
+    "cfgpp_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),
+    "cfgpp_vae_finalize": (_I, [_P]),
+    "cfgpp_vae_decode": (_I, [_P, _P, _P, _I, _P]),
+    "cfgpp_vae_flops": (C.c_double, [_P, _I]),
+    "cfgpp_vae_device_bytes": (C.c_double, [_P]),
+    "cfgpp_op_softmax_rows": (_I, [_P, _L, _I, _P]),
+    "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

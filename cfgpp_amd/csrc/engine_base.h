@@ -1,0 +1,278 @@
+// Shared executor infrastructure of the UNet and VAE engines: host-side parameter table, weight
+// repacking + upload, shape-keyed activation pool (halo-padded NHWC), and the launch-plan builder
+// (closures over preallocated buffers).  Header-only; each engine TU gets its own copy.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cfgpp.h"
+#include "igemm.h"
+
+namespace {
+
+
+struct HostParam {
+    std::vector<long> shape;
+    std::vector<half_t> h;     // matrices / conv kernels
+    std::vector<float> f;      // 1-D params (bias, norm) and conv_in
+    bool is_matrix = false;
+    bool loaded = false;
+    long numel() const { long n = 1; for (long s : shape) n *= s; return n; }
+};
+
+struct Tensor {   // halo-padded NHWC fp16 activation
+    half_t* p = nullptr;
+    int H = 0, W = 0, C = 0;
+};
+
+using Op = std::function<int(hipStream_t, int /*rows*/)>;
+
+
+struct EngineBase {
+    int max_rows = 1;
+    int norm_groups = 32;
+    std::map<std::string, HostParam> params;
+    std::vector<void*> allocs;
+    double dev_bytes = 0;
+    double macs_per_row = 0;        // conv/linear MACs per batch row per forward
+    double attn_macs_per_row = 0;
+
+    std::vector<Op> plan;           // forward
+    // per-op tags of `plan` for the profiler: kernel family + algorithmic MACs per batch row
+    std::vector<int> plan_kind;     // 0 igemm (conv/linear), 1 attention, 2 norm (GN/LN), 3 small
+    std::vector<double> plan_macs;
+    std::vector<std::string> plan_desc;
+    void tag(int kind, double macs, const std::string& desc = "") {
+        plan_kind.resize(plan.size(), 3); plan_macs.resize(plan.size(), 0.0); plan_desc.resize(plan.size());
+        if (!plan.empty()) { plan_kind.back() = kind; plan_macs.back() = macs; plan_desc.back() = desc; }
+    }
+    // activation pool, keyed by shape (halo stays zero for ever)
+    std::map<std::tuple<int, int, int>, std::vector<half_t*>> pool;
+    float* d_gn_stats = nullptr;
+
+    void* dmalloc(size_t bytes, bool zero = true) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (zero) hipMemset(p, 0, bytes);
+        allocs.push_back(p);
+        dev_bytes += (double)bytes;
+        return p;
+    }
+    Tensor acq(int H, int W, int C) {
+        auto key = std::make_tuple(H, W, C);
+        auto& fl = pool[key];
+        Tensor t; t.H = H; t.W = W; t.C = C;
+        if (!fl.empty()) { t.p = fl.back(); fl.pop_back(); return t; }
+        t.p = (half_t*)dmalloc((size_t)max_rows * (H + 2) * (W + 2) * C * sizeof(half_t));
+        return t;
+    }
+    void rel(const Tensor& t) { if (t.p) pool[std::make_tuple(t.H, t.W, t.C)].push_back(t.p); }
+    ~EngineBase() { for (void* p : allocs) hipFree(p); }
+};
+
+void expect(EngineBase* u, const std::string& key, std::vector<long> shape, bool matrix) {
+    HostParam hp; hp.shape = std::move(shape); hp.is_matrix = matrix;
+    u->params[key] = std::move(hp);
+}
+void expect_linear(EngineBase* u, const std::string& p, long out, long in, bool bias = true) {
+    expect(u, p + ".weight", {out, in}, true);
+    if (bias) expect(u, p + ".bias", {out}, false);
+}
+void expect_conv(EngineBase* u, const std::string& p, long out, long in, int k) {
+    expect(u, p + ".weight", {out, in, k, k}, true);
+    expect(u, p + ".bias", {out}, false);
+}
+void expect_norm(EngineBase* u, const std::string& p, long c) {
+    expect(u, p + ".weight", {c}, false);
+    expect(u, p + ".bias", {c}, false);
+}
+void expect_resnet(EngineBase* u, const std::string& p, long cin, long cout, long temb) {
+    expect_norm(u, p + ".norm1", cin);
+    expect_conv(u, p + ".conv1", cout, cin, 3);
+    expect_linear(u, p + ".time_emb_proj", cout, temb);
+    expect_norm(u, p + ".norm2", cout);
+    expect_conv(u, p + ".conv2", cout, cout, 3);
+    if (cin != cout) expect_conv(u, p + ".conv_shortcut", cout, cin, 1);
+}
+void expect_transformer(EngineBase* u, const std::string& p, long c, int depth, long cross) {
+    expect_norm(u, p + ".norm", c);
+    // proj_in/out: conv1x1 [c,c,1,1] (SD1.5) or linear [c,c] (SDXL): accept either (numel equal)
+    expect(u, p + ".proj_in.weight", {c, c}, true);  expect(u, p + ".proj_in.bias", {c}, false);
+    expect(u, p + ".proj_out.weight", {c, c}, true); expect(u, p + ".proj_out.bias", {c}, false);
+    for (int k = 0; k < depth; ++k) {
+        const std::string b = p + ".transformer_blocks." + std::to_string(k);
+        expect_norm(u, b + ".norm1", c); expect_norm(u, b + ".norm2", c); expect_norm(u, b + ".norm3", c);
+        expect_linear(u, b + ".attn1.to_q", c, c, false); expect_linear(u, b + ".attn1.to_k", c, c, false);
+        expect_linear(u, b + ".attn1.to_v", c, c, false); expect_linear(u, b + ".attn1.to_out.0", c, c, true);
+        expect_linear(u, b + ".attn2.to_q", c, c, false); expect_linear(u, b + ".attn2.to_k", c, cross, false);
+        expect_linear(u, b + ".attn2.to_v", c, cross, false); expect_linear(u, b + ".attn2.to_out.0", c, c, true);
+        expect_linear(u, b + ".ff.net.0.proj", 8 * c, c, true);
+        expect_linear(u, b + ".ff.net.2", c, 4 * c, true);
+    }
+}
+
+struct Builder {
+    EngineBase* u;
+    bool ok = true;
+    std::string err;
+
+    HostParam* get(const std::string& key) {
+        auto it = u->params.find(key);
+        if (it == u->params.end() || !it->second.loaded) { ok = false; err = "missing parameter " + key; return nullptr; }
+        return &it->second;
+    }
+    template <typename T>
+    T* upload(const std::vector<T>& v) {
+        T* d = (T*)u->dmalloc(v.size() * sizeof(T), false);
+        if (!d) { ok = false; err = "hipMalloc failed"; return nullptr; }
+        if (hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { ok = false; err = "hipMemcpy failed"; }
+        return d;
+    }
+    void drop(const std::string& key) { auto& p = u->params[key]; std::vector<half_t>().swap(p.h); std::vector<float>().swap(p.f); }
+
+    float* f32(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        float* d = upload(p->f); drop(key); return d;
+    }
+    // [N][K] as is (linear, or conv1x1 OIHW)
+    half_t* linear(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        half_t* d = upload(p->h); drop(key); return d;
+    }
+    // OIHW -> [O][kh*kw][I]
+    half_t* conv3(const std::string& key) {
+        HostParam* p = get(key); if (!p) return nullptr;
+        const long O = p->shape[0], I = p->shape[1];
+        std::vector<half_t> r((size_t)O * 9 * I);
+        for (long o = 0; o < O; ++o)
+            for (long i = 0; i < I; ++i)
+                for (int t = 0; t < 9; ++t) r[((size_t)o * 9 + t) * I + i] = p->h[((size_t)o * I + i) * 9 + t];
+        half_t* d = upload(r); drop(key); return d;
+    }
+    // concat rows of several [n_i][K] matrices
+    half_t* concat(const std::vector<std::string>& keys) {
+        std::vector<half_t> r;
+        for (auto& k : keys) { HostParam* p = get(k); if (!p) return nullptr; r.insert(r.end(), p->h.begin(), p->h.end()); }
+        half_t* d = upload(r);
+        for (auto& k : keys) drop(k);
+        return d;
+    }
+    // GEGLU packing: within every 64 packed rows, [0,32) value rows f, [32,64) gate rows 4C+f
+    void geglu(const std::string& pfx, long C, half_t** w, float** b) {
+        HostParam* pw = get(pfx + ".weight"); HostParam* pb = get(pfx + ".bias");
+        if (!pw || !pb) return;
+        const long F = 4 * C;
+        std::vector<half_t> rw((size_t)2 * F * C); std::vector<float> rb((size_t)2 * F);
+        for (long f = 0; f < F; ++f) {
+            const long pv = (f / 32) * 64 + (f % 32), pg = pv + 32;
+            std::memcpy(&rw[(size_t)pv * C], &pw->h[(size_t)f * C], C * sizeof(half_t));
+            std::memcpy(&rw[(size_t)pg * C], &pw->h[(size_t)(F + f) * C], C * sizeof(half_t));
+            rb[pv] = pb->f[f]; rb[pg] = pb->f[F + f];
+        }
+        *w = upload(rw); *b = upload(rb);
+        drop(pfx + ".weight"); drop(pfx + ".bias");
+    }
+};
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// generic igemm op helpers ----------------------------------------------------
+IGemmArgs base_args() {
+    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; return a;
+}
+
+struct Plan {
+    EngineBase* u;
+    Builder* B;
+    std::vector<Op>* ops;
+
+    // conv3x3 on padded NHWC.  amode 1 normal, 2 stride-2 (src is 2H x 2W), 3 upsample (src is H/2 x W/2)
+    void conv3x3(const Tensor& src, const Tensor& dst, const half_t* w, const float* bias, int amode,
+                 const float* temb, int temb_ld, const Tensor* resid) {
+        IGemmArgs a = base_args();
+        a.a0 = src.p; a.C0 = src.C; a.taps = 9; a.amode = amode; a.H = dst.H; a.W = dst.W;
+        a.w = w; a.N = dst.C; a.K = 9 * src.C; a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
+        a.rows_per_batch = dst.H * dst.W;
+        if (resid) { a.resid = resid->p; a.rmode = 1; a.rld = resid->C; }
+        a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * 9.0 * src.C;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * 9.0 * src.C, "conv3x3 amode=" + std::to_string(amode) + " HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(9 * src.C) + (resid ? " +res" : "") + (temb ? " +temb" : ""));
+    }
+    // 1x1 conv over (src0 || src1) padded -> padded
+    void conv1x1(const Tensor& s0, const Tensor* s1, const Tensor& dst, const half_t* w, const float* bias) {
+        IGemmArgs a = base_args();
+        a.a0 = s0.p; a.C0 = s0.C; if (s1) { a.a1 = s1->p; a.C1 = s1->C; }
+        a.amode = 1; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = a.C0 + a.C1; a.bias = bias;
+        a.rows_per_batch = dst.H * dst.W; a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * a.K;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * a.K, "conv1x1 HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(a.K));
+    }
+    // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
+    void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
+                int tokens, int epi = EPI_STORE) {
+        IGemmArgs a = base_args();
+        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias;
+        a.resid = resid; a.rmode = 0; a.rld = N; a.out = out; a.omode = 0;
+        a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
+        u->macs_per_row += (double)tokens * N * K;
+        ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)tokens * N * K, std::string(epi == EPI_GEGLU ? "geglu" : "linear") + " HW=" + std::to_string(tokens) + " N=" + std::to_string(N) + " K=" + std::to_string(K) + (resid ? " +res" : ""));
+    }
+    // tokens -> padded NHWC with residual from a padded tensor (Transformer2D proj_out)
+    void linear_to_padded(const half_t* A, int K, const Tensor& dst, const half_t* w, const float* bias, const Tensor& resid) {
+        IGemmArgs a = base_args();
+        a.a0 = A; a.C0 = K; a.amode = 0; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = K; a.bias = bias;
+        a.resid = resid.p; a.rmode = 1; a.rld = resid.C; a.out = dst.p; a.omode = 1; a.old = dst.C;
+        a.epi = EPI_STORE; a.rows_per_batch = dst.H * dst.W;
+        const int HW = dst.H * dst.W;
+        u->macs_per_row += (double)HW * dst.C * K;
+        ops->push_back([a, HW](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * HW; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, (double)HW * dst.C * K, "proj_out HW=" + std::to_string(HW) + " N=" + std::to_string(dst.C) + " K=" + std::to_string(K));
+    }
+    // projection into head-major buffers
+    void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
+               half_t* q, half_t* k, half_t* vt, int q_tok_pad, int tok_pad, bool count = true) {
+        IGemmArgs a = base_args();
+        const int d = C / nheads;
+        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.epi = EPI_HEADS;
+        a.rows_per_batch = tokens; a.hq = q; a.hk = k; a.hvt = vt; a.part0 = part0; a.part_width = C;
+        a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
+        if (count) u->macs_per_row += (double)tokens * N * K;
+        ops->push_back([a, tokens](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * tokens; return igemm_launch(b, s); });
+        if (ops == &u->plan) u->tag(0, count ? (double)tokens * N * K : 0.0, "heads HW=" + std::to_string(tokens) + " N=" + std::to_string(N) + " K=" + std::to_string(K));
+    }
+    void groupnorm(const Tensor& s0, const Tensor* s1, half_t* dst, bool dst_padded, const float* g, const float* b,
+                   float eps, bool silu) {
+        EngineBase* uu = u;
+        const half_t* p0 = s0.p; const half_t* p1 = s1 ? s1->p : nullptr;
+        const int H = s0.H, W = s0.W, C0 = s0.C, C1 = s1 ? s1->C : 0, G = u->norm_groups;
+        ops->push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_groupnorm(p0, p1, dst, g, b, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
+                                      dst_padded ? 1 : 0, s);
+        });
+        if (ops == &u->plan) u->tag(2, 0.0, "groupnorm HW=" + std::to_string(H * W) + " C=" + std::to_string(C0 + C1));
+    }
+    void layernorm(const half_t* x, half_t* y, const float* g, const float* b, int tokens, int C) {
+        ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_layernorm(x, y, g, b, (long)rows * tokens, C, 1e-5f, s); });
+        if (ops == &u->plan) u->tag(2, 0.0, "layernorm HW=" + std::to_string(tokens) + " C=" + std::to_string(C));
+    }
+    void attention(const half_t* q, const half_t* k, const half_t* vt, half_t* o, int nheads, int d, int nq, int nk,
+                   int q_tok_pad, int k_tok_pad) {
+        u->attn_macs_per_row += 2.0 * (double)nheads * nq * nk * d;
+        ops->push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_attention(q, k, vt, o, rows, nheads, d, nq, nk, q_tok_pad, k_tok_pad, s);
+        });
+        if (ops == &u->plan) u->tag(1, 2.0 * (double)nheads * nq * nk * d, "self_attn heads=" + std::to_string(nheads) + " N=" + std::to_string(nq) + " d=" + std::to_string(d));
+    }
+};
+
+}  // namespace

@@ -7,9 +7,9 @@
 // value is rounded to fp16 once - exactly the value the following fp16 conv /
 // linear consumes in the reference.
 //
-// Two launches: (1) partial sums per (n, group) with coalesced 16-B reads,
-// LDS-atomics per block, one global atomic per (block, group);
-// (2) apply.  Algorithmic bytes per element: 2 (stats read) + 2 (apply read) + 2 (write).
+// Three launches, all deterministic (no atomics, fixed summation order -> bit-identical runs):
+// (1) per-block partial sums with coalesced 16-B reads, (2) a tiny fixed-order finalize to
+// mean / rstd, (3) apply.  Algorithmic bytes per element: 2 (stats read) + 2 (apply read) + 2 (write).
 #include "common.h"
 
 namespace {
@@ -20,7 +20,8 @@ struct GNArgs {
     half_t* dst;
     const float* gamma;   // [C]
     const float* beta;    // [C]
-    float* stats;         // [N][G][2] fp32 (sum, sumsq), zeroed before the stats kernel
+    float* stats;         // [N][nblk][G][2] fp32 per-block partial (sum, sumsq)
+    const float* mean_rstd;   // [N][G][2] written by gn_finalize_kernel
     int N, H, W;
     int C0, C1;           // channels of src0 / src1 (C = C0 + C1), both multiples of 8
     int G;                // groups
@@ -34,9 +35,12 @@ __device__ __forceinline__ long pad_off(int n, int y, int x, int H, int W) {
     return ((long)(n * (H + 2) + y + 1) * (W + 2) + x + 1);
 }
 
+// Pass 1: per-(sample, pixel-block) partial sums of every group, DETERMINISTIC (no atomics): each thread
+// sums 8 channels over its pixels, the block combines them through LDS in a fixed order and writes
+// part[n][blk][g][2].  Pass 2 (gn_finalize_kernel) reduces the blocks in a fixed order to mean / rstd.
 __global__ void __launch_bounds__(256)
 gn_stats_kernel(GNArgs a) {
-    __shared__ float s_acc[2 * 64];   // up to 64 groups
+    __shared__ float s_part[256][16];   // [thread][8 sums | 8 sums of squares]
     const int C = a.C0 + a.C1;
     const int cpg = C / a.G;
     const int chunks = C / 8;
@@ -44,9 +48,8 @@ gn_stats_kernel(GNArgs a) {
     const int HW = a.H * a.W;
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
-    for (int i = threadIdx.x; i < 2 * a.G; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
     const int ppi = max(1, (int)blockDim.x / chunks);        // pixels per iteration
+    float gsum = 0.f, gsq = 0.f;                             // thread g < G owns group g
     for (int cbase = 0; cbase < chunks; cbase += blockDim.x) {
         int chunk, psub;
         if (chunks <= (int)blockDim.x) { chunk = threadIdx.x % chunks; psub = threadIdx.x / chunks; }
@@ -65,20 +68,51 @@ gn_stats_kernel(GNArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { float f = (float)v[k]; s[k] += f; q[k] += f * f; }
             }
-            // flush the 8 channels into their groups
-            int g_cur = c / cpg; float gs = 0.f, gq = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int g = (c + k) / cpg;
-                if (g != g_cur) { atomicAdd(&s_acc[2 * g_cur], gs); atomicAdd(&s_acc[2 * g_cur + 1], gq); g_cur = g; gs = 0.f; gq = 0.f; }
-                gs += s[k]; gq += q[k];
-            }
-            atomicAdd(&s_acc[2 * g_cur], gs); atomicAdd(&s_acc[2 * g_cur + 1], gq);
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s_part[threadIdx.x][k] = s[k]; s_part[threadIdx.x][8 + k] = q[k]; }
+        __syncthreads();
+        if ((int)threadIdx.x < a.G) {
+            // channels of group g inside this pass: [max(g*cpg, cbase*8), min((g+1)*cpg, (cbase+blockDim)*8, C))
+            const int g = threadIdx.x;
+            const int pass_lo = cbase * 8, pass_hi = min(C, (cbase + (int)blockDim.x) * 8);
+            const int c_lo = max(g * cpg, pass_lo), c_hi = min((g + 1) * cpg, pass_hi);
+            for (int c = c_lo; c < c_hi; ++c) {
+                const int chunk_l = (c >> 3) - cbase, k = c & 7;
+                if (chunks <= (int)blockDim.x) {
+                    for (int ps = 0; ps < ppi; ++ps) { gsum += s_part[ps * chunks + chunk_l][k]; gsq += s_part[ps * chunks + chunk_l][8 + k]; }
+                } else {
+                    gsum += s_part[chunk_l][k]; gsq += s_part[chunk_l][8 + k];
+                }
+            }
+        }
+        __syncthreads();
         if (chunks <= (int)blockDim.x) break;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * a.G; i += blockDim.x) atomicAdd(&a.stats[(long)n * a.G * 2 + i], s_acc[i]);
+    if ((int)threadIdx.x < a.G) {
+        float* dst = a.stats + (((long)n * gridDim.x + blockIdx.x) * a.G + threadIdx.x) * 2;
+        dst[0] = gsum; dst[1] = gsq;
+    }
+}
+
+// Pass 2: fixed-order reduction over the nblk pixel-blocks -> (mean, rstd) per (sample, group).
+// One 64-lane wave per (n, g): lane l sums blocks l, l+64, ... in order, then a fixed xor-shuffle tree.
+__global__ void __launch_bounds__(64)
+gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, int nblk, int G, float inv_cnt, float eps) {
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+    float s = 0.f, q = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 64) {
+        const float* p = part + (((long)n * nblk + b) * G + g) * 2;
+        s += p[0]; q += p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (threadIdx.x == 0) {
+        const float mean = s * inv_cnt;
+        float var = q * inv_cnt - mean * mean;
+        var = var < 0.f ? 0.f : var;
+        mr[((long)n * G + g) * 2] = mean; mr[((long)n * G + g) * 2 + 1] = rsqrtf(var + eps);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -91,13 +125,8 @@ gn_apply_kernel(GNArgs a) {
     const int HW = a.H * a.W;
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
-    const float inv_cnt = 1.0f / ((float)cpg * (float)HW);
     for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
-        const float sum = a.stats[((long)n * a.G + g) * 2], sq = a.stats[((long)n * a.G + g) * 2 + 1];
-        const float mean = sum * inv_cnt;
-        float var = sq * inv_cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        s_mean[g] = mean; s_rstd[g] = rsqrtf(var + a.eps);
+        s_mean[g] = a.mean_rstd[((long)n * a.G + g) * 2]; s_rstd[g] = a.mean_rstd[((long)n * a.G + g) * 2 + 1];
     }
     __syncthreads();
     const int ppi = max(1, (int)blockDim.x / chunks);
@@ -192,12 +221,73 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const flo
     }
 }
 
+// ---- row softmax in place (VAE mid-block attention: one 512-wide head, 4096 / 16384 keys) --------
+template <int MAXC>   // max 16-B chunks per thread (ncols <= 256*8*MAXC)
+__global__ void __launch_bounds__(256)
+softmax_rows_kernel(half_t* __restrict__ s, int ncols) {
+    __shared__ float red[8];
+    half_t* row = s + (long)blockIdx.x * ncols;
+    const int nchunks = ncols / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    float v[MAXC][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = tid + j * 256;
+        if (c < nchunks) {
+            const half8_t h = *reinterpret_cast<const half8_t*>(row + c * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[j][k] = (float)h[k] * 1.4426950408889634f; mx = fmaxf(mx, v[j][k]); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = tid + j * 256;
+        if (c < nchunks) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[j][k] = __builtin_amdgcn_exp2f(v[j][k] - mx); sum += v[j][k]; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wid] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+        const int c = tid + j * 256;
+        if (c < nchunks) {
+            half8_t o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (half_t)(v[j][k] * inv);
+            *reinterpret_cast<half8_t*>(row + c * 8) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
+int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream) {
+    CFGPP_REQUIRE(s && rows > 0 && ncols % 8 == 0 && ncols <= 256 * 8 * 8, "softmax_rows: ncols=%d (multiple of 8, <= 16384)", ncols);
+    hipStream_t st = (hipStream_t)stream;
+    const int need = cdiv(ncols / 8, 256);
+    if (need <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, dim3(rows), dim3(256), 0, st, (half_t*)s, ncols);
+    else hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(rows), dim3(256), 0, st, (half_t*)s, ncols);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
 // GroupNorm(+SiLU) over the channel-concat of src0[N,H+2,W+2,C0] and src1[N,H+2,W+2,C1]
-// (src1 may be NULL / C1 = 0).  stats: device scratch of N*G*2 floats.
+// (src1 may be NULL / C1 = 0).  stats: device scratch of N * (1024*G*2 + G*2) floats.
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
                        int dst_padded, void* stream) {
@@ -208,17 +298,22 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
     hipStream_t s = (hipStream_t)stream;
     GNArgs a;
     a.src0 = (const half_t*)src0; a.src1 = (const half_t*)src1; a.dst = (half_t*)dst;
-    a.gamma = gamma; a.beta = beta; a.stats = stats;
+    a.gamma = gamma; a.beta = beta;
     a.N = N; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.G = G; a.eps = eps; a.silu = silu;
     a.dst_padded = dst_padded;
     const int HW = H * W;
-    // aim for >= ~1024 blocks while keeping >= 16 pixels per thread-column
+    // aim for >= ~1024 blocks, >= 16 pixels per block, and at most 1024 blocks per sample (scratch bound)
     int ppb = 64;
     while (ppb > 16 && (long)N * cdiv(HW, ppb) < 1024) ppb >>= 1;
+    while (cdiv(HW, ppb) > 1024) ppb <<= 1;
     a.pix_per_block = ppb;
-    CFGPP_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(float) * 2 * (size_t)N * G, s));
-    dim3 grid(cdiv(HW, ppb), N);
+    const int nblk = cdiv(HW, ppb);
+    float* part = stats;
+    float* mr = stats + (size_t)N * 1024 * G * 2;
+    a.stats = part; a.mean_rstd = mr;
+    dim3 grid(nblk, N);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, s, part, mr, nblk, G, 1.0f / ((float)(C / G) * (float)HW), eps);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, s, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;

@@ -16,7 +16,8 @@ namespace {
 template <typename TIN>
 __global__ void __launch_bounds__(256)
 conv_in_kernel(const TIN* __restrict__ z, half_t* __restrict__ out, const float* __restrict__ w,
-               const float* __restrict__ bias, int R, int zB, int Cin, int H, int W, int Cout) {
+               const float* __restrict__ bias, int R, int zB, int Cin, int H, int W, int Cout,
+               const float* __restrict__ pre_w, const float* __restrict__ pre_b, float in_scale) {
     constexpr int TP = 16;                 // pixels per block
     __shared__ float patch[TP][9 * 8];
     const int r = blockIdx.y;
@@ -31,7 +32,18 @@ conv_in_kernel(const TIN* __restrict__ z, half_t* __restrict__ out, const float*
         float v = 0.f;
         if (p < HW) {
             const int y = p / W + tap / 3 - 1, x = p % W + tap % 3 - 1;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = (float)z[((long)(zb * Cin + ci) * H + y) * W + x];
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                if (pre_w) {
+                    // pointwise pre-conv folded in (VAE: z / scaling_factor -> post_quant_conv 1x1), applied to
+                    // in-bounds pixels only so the zero padding of the 3x3 conv stays zero
+                    float acc = pre_b ? pre_b[ci] : 0.f;
+                    for (int j = 0; j < Cin; ++j)
+                        acc += pre_w[ci * Cin + j] * (float)(half_t)((float)z[((long)(zb * Cin + j) * H + y) * W + x] * in_scale);
+                    v = acc;
+                } else {
+                    v = (float)z[((long)(zb * Cin + ci) * H + y) * W + x] * in_scale;
+                }
+            }
         }
         // the reference feeds the UNet an fp16 sample under autocast: round the input once
         patch[tp][k] = (float)(half_t)v;
@@ -203,18 +215,24 @@ __global__ void f16_to_f32_rows_kernel(const half_t* __restrict__ in, float* __r
 
 extern "C" {
 
-int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
-                     int R, int zB, int Cin, int H, int W, int Cout, void* stream) {
+int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w, const float* bias,
+                        int R, int zB, int Cin, int H, int W, int Cout, const float* pre_w, const float* pre_b,
+                        float in_scale, void* stream) {
     CFGPP_REQUIRE(Cin >= 1 && Cin <= 8, "conv_in: Cin=%d (<= 8)", Cin);
     CFGPP_REQUIRE(z && out && w && R > 0 && zB > 0, "conv_in: bad args");
     dim3 grid(cdiv((long)H * W, 16), R);
     hipStream_t s = (hipStream_t)stream;
     if (z_is_half)
-        hipLaunchKernelGGL(conv_in_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout);
+        hipLaunchKernelGGL(conv_in_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout, pre_w, pre_b, in_scale);
     else
-        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout);
+        hipLaunchKernelGGL(conv_in_kernel<float>, grid, dim3(256), 0, s, (const float*)z, (half_t*)out, w, bias, R, zB, Cin, H, W, Cout, pre_w, pre_b, in_scale);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
+                     int R, int zB, int Cin, int H, int W, int Cout, void* stream) {
+    return cfgpp_op_conv_in_ex(z, z_is_half, out, w, bias, R, zB, Cin, H, W, Cout, nullptr, nullptr, 1.0f, stream);
 }
 
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,

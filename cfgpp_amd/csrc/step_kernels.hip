@@ -19,7 +19,13 @@
 
 namespace {
 
-__device__ __forceinline__ float h_round(float x) { return (float)(half_t)x; }  // RNE to fp16
+// RNE to fp16 of a value that has ALREADY been rounded to fp32 (torch computes the fp16 result of an
+// op in fp32 and then rounds: two roundings).  The empty asm makes the fp32 value opaque so the compiler
+// cannot fuse mul+convert into v_fma_mixlo_f16, which rounds the exact product ONCE and differs on ties.
+__device__ __forceinline__ float h_round(float x) {
+    asm volatile("" : "+v"(x));
+    return (float)(half_t)x;
+}
 
 // eps_hat = eps_uc + lam*(eps_c - eps_uc) with fp16 rounding after each op
 __device__ __forceinline__ float cfg_mix_h(float uc, float c, float lam) {
@@ -79,7 +85,7 @@ kdiff_input_kernel(const half_t* __restrict__ x, half_t* __restrict__ xc, float 
     for (; i < n; i += stride) {
         float v = (float)x[i];
         v = mode == 0 ? __fdiv_rn(v, s) : __fmul_rn(v, s);
-        xc[i] = (half_t)v;
+        xc[i] = (half_t)h_round(v);
     }
 }
 
@@ -150,15 +156,15 @@ kdiff_denoise_kernel(const half_t* __restrict__ x, const half_t* __restrict__ ep
     for (; i < n; i += stride) {
         const float xv = (float)x[i], uc = (float)eps_uc[i], cc = (float)eps_c[i];
         const float hat = cfg_mix_h(uc, cc, lam);
-        den[i] = (half_t)__fsub_rn(xv, h_round(__fmul_rn(hat, sigma)));
-        uden[i] = (half_t)__fsub_rn(xv, h_round(__fmul_rn(uc, sigma)));
+        den[i] = (half_t)h_round(__fsub_rn(xv, h_round(__fmul_rn(hat, sigma))));
+        uden[i] = (half_t)h_round(__fsub_rn(xv, h_round(__fmul_rn(uc, sigma))));
     }
 }
 // mode 0: out = h( h(x*a) - h(y*b) )                 x_2 / x of DPM-Solver++(2S)   (latent_diffusion.py:428,435,804)
 // mode 1: out = h( h(y - h(z*b)) + h(x*a) )          CFG++ 2S final update          (latent_diffusion.py:811)
 // mode 2: out = h( x + h(y*a) )                      ancestral noise                (latent_diffusion.py:379,438)
 __global__ void __launch_bounds__(256)
-lincomb_kernel(half_t* __restrict__ out, const half_t* __restrict__ x, const half_t* __restrict__ y,
+lincomb_kernel(half_t* out, const half_t* x, const half_t* __restrict__ y,
                const half_t* __restrict__ z, float a, float b, int mode, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
@@ -168,7 +174,7 @@ lincomb_kernel(half_t* __restrict__ out, const half_t* __restrict__ x, const hal
         if (mode == 0) r = __fsub_rn(h_round(__fmul_rn(xv, a)), h_round(__fmul_rn(yv, b)));
         else if (mode == 1) r = __fadd_rn(h_round(__fsub_rn(yv, h_round(__fmul_rn((float)z[i], b)))), h_round(__fmul_rn(xv, a)));
         else r = __fadd_rn(xv, h_round(__fmul_rn(yv, a)));
-        out[i] = (half_t)r;
+        out[i] = (half_t)h_round(r);
     }
 }
 

@@ -120,8 +120,13 @@ class StableDiffusion:
 
     def _get_vae(self):
         if self.vae is None:
-            from .vae import TorchVAE
-            self.vae = TorchVAE(self.cfg.vae_scale, device=self.work_device, **self._vae_kwargs)
+            if self.work_device.type == "cuda":
+                from .vae import HipVAE          # decoder on the HIP kernels; no fallback
+                self.vae = HipVAE(self.cfg.vae_scale, self.latent_hw, max_batch=self.max_batch, device=self.work_device,
+                                  **self._vae_kwargs)
+            else:                                # only reachable with an injected (test) engine on CPU
+                from .vae import TorchVAE
+                self.vae = TorchVAE(self.cfg.vae_scale, device=self.work_device, dtype=torch.float32, **self._vae_kwargs)
         return self.vae
 
     def encode(self, x):

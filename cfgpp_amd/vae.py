@@ -1,12 +1,15 @@
-"""AutoencoderKL decode / encode (SURVEY.md 8a row a12, 8f row f1 "next").
+"""AutoencoderKL decode / encode.
 
-Interim implementation: the diffusers-0.27.1 AutoencoderKL architecture
-(SD1.5 ``vae`` / ``madebyollin/sdxl-vae-fp16-fix``: block_out_channels
-(128,256,512,512), 2 layers per block, 4 latent channels) restated functionally
-on torch-ROCm ops with seeded synthetic weights.  It sits OUTSIDE the per-step
-path (once per image) and is the next component to move onto the hand-written
-conv / GroupNorm / attention kernels; the benchmark includes its time in
-images/sec and says so.
+``HipVAE``   - the DECODER on the hand-written HIP kernels (``csrc/vae.hip`` behind the C ABI:
+               implicit-GEMM convs incl. fused upsample, GroupNorm+SiLU, GEMM-softmax-GEMM mid-block
+               attention).  This is what ``solver.decode()`` runs on the GPU and what the benchmark times.
+``TorchVAE`` - the same diffusers-0.27.1 AutoencoderKL architecture (SD1.5 ``vae`` /
+               ``madebyollin/sdxl-vae-fp16-fix``: block_out_channels (128,256,512,512), 2 layers per
+               block, 4 latent channels) restated functionally on torch ops.  Used (a) on the CPU in
+               fp32 as the parity reference of ``HipVAE`` and in the CPU baseline, (b) for ``encode``
+               (image -> latent, only the inversion/edit solvers need it; once per image, still
+               torch-ROCm - the next thing to move).
+Weights: seeded synthetic in exact diffusers shapes / key names (no checkpoints offline).
 
 Reference call sites: latent_diffusion.py:117-129 (scale 0.18215),
 latent_sdxl.py:44,150-164 (``vae.config.scaling_factor`` = 0.13025).
@@ -180,3 +183,66 @@ class TorchVAE:
             noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
             mean = mean + torch.exp(0.5 * logvar) * noise
         return mean * self.scaling_factor
+
+
+class HipVAE:
+    """VAE whose ``decode`` runs on libcfgpp_hip.so (no MIOpen, no torch conv).  ``encode`` delegates to a
+    lazily built :class:`TorchVAE` with the same weights."""
+
+    def __init__(self, scaling_factor: float, latent_hw, max_batch: int = 1, device=None, state_dict=None, seed: int = 0):
+        import ctypes as C
+
+        from . import _lib
+        from ._lib import CfgppError, check
+        if not torch.cuda.is_available():
+            raise CfgppError("HipVAE needs a ROCm GPU; the HIP path has no CPU fallback")
+        self.lib = _lib.load()
+        dev = torch.device(device if device is not None else "cuda")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.scaling_factor = float(scaling_factor)
+        self.h, self.w = int(latent_hw[0]), int(latent_hw[1])
+        self.max_batch = int(max_batch)
+        self._sd = state_dict if state_dict is not None else synth_vae_state_dict(seed)
+        self._h = self.lib.cfgpp_vae_create(self.h, self.w, self.max_batch, self.scaling_factor, self.device.index)
+        if not self._h:
+            raise CfgppError("cfgpp_vae_create failed: " + _lib.last_error())
+        for k, v in self._sd.items():
+            if not (k.startswith("decoder.") or k.startswith("post_quant_conv.")):
+                continue
+            t = v.detach().cpu().contiguous()
+            dt = 1 if t.dtype == torch.float16 else 0
+            if dt == 0:
+                t = t.to(torch.float32)
+            shape = (C.c_long * t.dim())(*t.shape)
+            check(self.lib.cfgpp_vae_load_tensor(self._h, k.encode(), t.data_ptr(), dt, shape, t.dim()), f"cfgpp_vae_load_tensor({k})")
+        check(self.lib.cfgpp_vae_finalize(self._h), "cfgpp_vae_finalize")
+        self._torch = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+            self.lib.cfgpp_vae_destroy(h)
+            self._h = None
+
+    def decode(self, zt: torch.Tensor) -> torch.Tensor:
+        """zt [B,4,h,w] -> image [B,3,8h,8w] fp32 on the GPU (reference: latent_diffusion.py:123-129)."""
+        from ._lib import CfgppError, check
+        z = zt.to(device=self.device, dtype=torch.float32).contiguous()
+        B = int(z.shape[0])
+        if tuple(z.shape[1:]) != (4, self.h, self.w) or B > self.max_batch:
+            raise CfgppError(f"HipVAE.decode: latent {tuple(z.shape)} does not fit engine [<= {self.max_batch}, 4, {self.h}, {self.w}]")
+        img = torch.empty((B, 3, 8 * self.h, 8 * self.w), dtype=torch.float32, device=self.device)
+        check(self.lib.cfgpp_vae_decode(self._h, z.data_ptr(), img.data_ptr(), B, torch.cuda.current_stream().cuda_stream), "cfgpp_vae_decode")
+        return img
+
+    def encode(self, x, sample: bool = True, generator=None):
+        if self._torch is None:
+            self._torch = TorchVAE(self.scaling_factor, device=self.device, state_dict=self._sd)
+        return self._torch.encode(x, sample=sample, generator=generator)
+
+    def flops(self, B: int) -> float:
+        return float(self.lib.cfgpp_vae_flops(self._h, int(B)))

@@ -123,7 +123,24 @@ double cfgpp_unet_flops(cfgpp_unet* u, int rows);
 /* Bytes of device memory held (weights + activations). */
 double cfgpp_unet_device_bytes(cfgpp_unet* u);
 
+/* ---- VAE decoder engine (replaces `self.vae.decode(z / scale).sample`) ------
+ * latent_diffusion.py:123-129 (scale 0.18215), latent_sdxl.py:155-164 (vae.config.scaling_factor).
+ * Weights by diffusers AutoencoderKL keys (post_quant_conv.*, decoder.*).  img fp32 [B][3][8h][8w]. */
+typedef struct cfgpp_vae cfgpp_vae;
+cfgpp_vae* cfgpp_vae_create(int latent_h, int latent_w, int max_batch, float scaling_factor, int device_id);
+void cfgpp_vae_destroy(cfgpp_vae* v);
+int cfgpp_vae_load_tensor(cfgpp_vae* v, const char* key, const void* host, int dtype, const long* shape, int ndim);
+int cfgpp_vae_finalize(cfgpp_vae* v);
+int cfgpp_vae_decode(cfgpp_vae* v, const void* z, void* img, int B, void* stream);
+double cfgpp_vae_flops(cfgpp_vae* v, int B);
+double cfgpp_vae_device_bytes(cfgpp_vae* v);
+
 /* ---- single ops, exposed for parity tests and micro-benchmarks ------------- */
+int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream);
+int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w, const float* bias,
+                        int R, int zB, int Cin, int H, int W, int Cout, const float* pre_w, const float* pre_b,
+                        float in_scale, void* stream);
+/* stats: scratch of N*(1024*G*2 + G*2) floats (per-block partials + mean/rstd); deterministic, no atomics */
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
                        int dst_padded, void* stream);

@@ -113,7 +113,7 @@ def groupnorm(x0_pn, x1_pn, gamma, beta, G, eps, silu, dst_padded=True):
     H, W = Hp - 2, Wp - 2
     C1 = 0 if x1_pn is None else x1_pn.shape[3]
     C = C0 + C1
-    stats = torch.zeros(N * G * 2, dtype=torch.float32, device=DEV)
+    stats = torch.zeros(N * (1024 * G * 2 + G * 2), dtype=torch.float32, device=DEV)
     if dst_padded:
         dst = empty_pn(N, H, W, C)
     else:

@@ -84,3 +84,20 @@ def test_smoke_entry():
         pytest.skip("needs the MI355X")
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_unet_forward_is_bitwise_deterministic():
+    """no atomics anywhere on the path: two forwards of the same input are bit-identical"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import TINY_SD as cfg
+    from cfgpp_amd.weights import synth_state_dict
+    net = HipUNet(cfg, 4, (16, 16))
+    net.load_state_dict(synth_state_dict(cfg)).finalize()
+    g = torch.Generator().manual_seed(0)
+    net.set_context((torch.randn(4, 77, cfg.cross_attention_dim, generator=g) * 0.5))
+    z = torch.randn(2, 4, 16, 16, generator=g).cuda()
+    a = net.forward(z, 500.0).clone()
+    for _ in range(3):
+        assert torch.equal(net.forward(z, 500.0), a)
