@@ -247,11 +247,20 @@ def main():
                 for k in agg:
                     agg[k]["ms"] += pr[k]["ms"]
                     agg[k]["flops"] += pr[k]["flops"]
+        # HBM traffic of the same kernel family from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+        # separate --pmc runs, scripts/pmc_traffic.py); measured once per round and committed under profiles/.
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_{args.config}_b{B}.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         ig = agg["igemm"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/linear)", "achieved": round(ach, 1),
                               "peak": PEAK_MFMA_FP16 / 1e12, "unit": "TFLOP/s", "frac": round(ach / (PEAK_MFMA_FP16 / 1e12), 4),
-                              "traffic": None, "launches_per_forward": ig["launches"],
+                              "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, incl. the VAE's igemm launches)", "launches_per_forward": ig["launches"],
                               "avg_launch_us": round(ig["ms"] / 3 / max(ig["launches"], 1) * 1e3, 2),
                               "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in agg.items()},
                               "attention_TFLOPs": round(agg["attention"]["flops"] / (agg["attention"]["ms"] * 1e-3) / 1e12, 1)}

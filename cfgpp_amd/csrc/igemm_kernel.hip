@@ -322,29 +322,49 @@ igemm_kernel(const IGemmArgs p) {
         }
         const char* As = smem + cur * STAGE_BYTES;
         const char* Bs = As + BM * 128;
-        // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
-        half8_t xa[2][MT], wb[2][NT];
-        {
-            const int coff = ((0 | fhi) ^ fsw) << 4;
+        if constexpr (MT * NT <= 8) {
+            // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+            half8_t xa[2][MT], wb[2][NT];
+            {
+                const int coff = ((0 | fhi) ^ fsw) << 4;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+                for (int i = 0; i < MT; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
-                const int coff = ((((ks + 1) << 1) | fhi) ^ fsw) << 4;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) xa[(ks + 1) & 1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wb[(ks + 1) & 1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+                for (int j = 0; j < NT; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
             }
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+                    const int coff = ((((ks + 1) << 1) | fhi) ^ fsw) << 4;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][j], xa[ks & 1][i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < MT; ++i) xa[(ks + 1) & 1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wb[(ks + 1) & 1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][j], xa[ks & 1][i], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // 10 accumulator tiles per wave (256x320): no room for a second fragment set; 10 MFMAs per k-step
+            // (320 cycles) give the partner wave on the SIMD time to cover the LDS latency instead
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+                half8_t xa[MT], wb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keep one fragment set live: no hoisting of the next k-step's reads
+            }
         }
         if constexpr (GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
@@ -408,6 +428,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
+static int g_big_tiles = 1;
+extern "C" void cfgpp_igemm_set_big_tiles(int on) { g_big_tiles = on ? 1 : 0; }
 static int g_dbg = 0;
 extern "C" void cfgpp_igemm_set_debug(int flags) { g_dbg = flags; }   // ablation hooks are compiled out of the product kernel
 static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
@@ -488,6 +510,13 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         const long t256x64 = (long)cdiv(a.M, 256) * cdiv(a.N, 64);
         const bool n_odd64 = (a.N % 128) != 0;
         const int KT = a.K >> 6;
+        // 8-wave one-block-per-CU tiles (fewer tile bytes per FLOP): only when they fill the 256 CUs
+        const long t5 = (a.N % 320 == 0) ? (long)cdiv(a.M, 256) * (a.N / 320) : 0;
+        const long t4 = (a.N % 256 == 0) ? (long)cdiv(a.M, 256) * (a.N / 256) : 0;
+        auto fills = [](long t) { return t >= 224 && (t % 256 == 0 || t % 256 >= 160 || t >= 1024); };
+        if (g_big_tiles && a.epi != EPI_GEGLU && a.K >= 1280 && fills(t5)) cfg = 5;
+        else if (g_big_tiles && t4 >= 192 && (t4 % 256 == 0 || t4 % 256 >= 128 || t4 >= 512)) cfg = 4;
+        else
         if (t128 >= 256 && !n_odd64) cfg = 1;
         else if (t256x64 >= 256 && (n_odd64 || a.N <= 64)) cfg = 2;
         else if (t128 >= 200) cfg = 1;
@@ -501,6 +530,10 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         case 1: return glds ? launch_cfg<2, 2, 64, 64, true>(a, stream) : launch_cfg<2, 2, 64, 64, false>(a, stream);
         case 2: return glds ? launch_cfg<4, 1, 64, 64, true>(a, stream) : launch_cfg<4, 1, 64, 64, false>(a, stream);
         case 3: return glds ? launch_cfg<2, 2, 32, 32, true>(a, stream) : launch_cfg<2, 2, 32, 32, false>(a, stream);
+        // 8-wave, one-workgroup-per-CU tiles: fewer tile bytes per FLOP through the CU's memory->LDS path
+        case 4: return launch_cfg<2, 4, 128, 64, true>(a, stream);     // 256 x 256
+        case 5: return launch_cfg<4, 2, 64, 160, true>(a, stream);     // 256 x 320 (every SD/SDXL channel count is k*320)
+        case 6: return launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }

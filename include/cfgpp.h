@@ -170,9 +170,10 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
-void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64; +10 = register-staged variant */
+void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128; 11..13 = register-staged 1..3 */
 void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
 void cfgpp_igemm_set_debug(int flags);    /* benchmark ablation: bit0 skip tile loads, bit1 skip MFMA */
+void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x320 tiles (default) */
 void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */
 
 #ifdef __cplusplus

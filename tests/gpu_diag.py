@@ -154,6 +154,29 @@ def t_conv1(N=2, C0=128, C1=64, Cout=64, Hh=9, Ww=7):
     return H.err_stats(H.from_pn(got), ref)
 
 
+@case("igemm_big_tiles")
+def t_big():
+    """8-wave tiles (256x256, 256x320, 256x128): conv3x3 + bias + temb + residual, and a plain linear, vs fp32 torch"""
+    out = {}
+    x = rnd(2, 128, 24, 20, seed=80)
+    w = rnd(320, 128, 3, 3, scale=(9 * 128) ** -0.5, seed=81)
+    b = rnd(320, scale=0.1, seed=82)
+    temb = rnd(2, 320, scale=0.5, seed=83)
+    res = rnd(2, 320, 24, 20, seed=84)
+    ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
+    a = rnd(700, 256, seed=85)
+    wl = rnd(640, 256, scale=1 / 16, seed=86)
+    bl = rnd(640, scale=0.1, seed=87)
+    refl = a @ wl.t() + bl
+    for c in (4, 5, 6):
+        H.lib().cfgpp_igemm_force_config(c)
+        got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
+        out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
+        out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
+    H.lib().cfgpp_igemm_force_config(0)
+    return out
+
+
 @case("igemm_tail_split")
 def t_tail():
     """K-split tail path (few tiles, long K): conv3x3 + residual, GEGLU and heads epilogues through
@@ -432,7 +455,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     print("[diag] device:", torch.cuda.get_device_name(0), flush=True)
-    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_tail(); t_gn(); t_ln(); t_attn(); t_heads()
+    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_big(); t_tail(); t_gn(); t_ln(); t_attn(); t_heads()
     t_cio(); t_small(); t_step()
     t_unet_tiny_sd(); t_unet_tiny_xl()
     if not args.quick:

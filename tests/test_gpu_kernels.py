@@ -67,6 +67,10 @@ def test_conv1x1_two_concatenated_sources(diag):
     _check(diag, diag.t_conv1, "conv1x1_two_sources")
 
 
+def test_igemm_8wave_tiles(diag):
+    _check(diag, diag.t_big, "igemm_big_tiles")
+
+
 def test_igemm_ksplit_tail_path(diag):
     _check(diag, diag.t_tail, "igemm_tail_split")
 
