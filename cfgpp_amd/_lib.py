@@ -76,6 +76,7 @@ PROTOTYPES = {
     "cfgpp_op_igemm_heads": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_igemm_force_config": (None, [_I]),
     "cfgpp_igemm_set_staging": (None, [_I]),
+    "cfgpp_igemm_set_staged_epilogue": (None, [_I]),
     "cfgpp_igemm_set_big_tiles": (None, [_I]),
     "cfgpp_igemm_set_debug": (None, [_I]),
     "cfgpp_igemm_set_tail_split": (None, [_I]),

@@ -41,6 +41,7 @@ struct IGemmArgs {
     int n_main;               // tiles [0, n_main) are computed whole by one block each
     int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
     float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
+    int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
     int dbg;                  // ablation (benchmarks only): bit0 = no tile loads after the first, bit1 = no MFMA
 };
 

@@ -137,6 +137,120 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     }
 }
 
+// EPI_STORE through LDS: the MFMA accumulator layout gives each lane 4 consecutive features of ONE row,
+// i.e. 8-byte stores scattered over 32 rows per instruction (and the same pattern for the residual
+// read).  Here each wave transposes its 32 x WTN slab through a private LDS region and then moves whole
+// row segments (WTN*2 bytes contiguous, 16 B per lane): coalesced residual loads and output stores.
+// bias / time-embedding are added in fp32 before the (single) rounding to fp16; the residual is added to
+// the fp16 value, which is exactly the reference's `conv(...)` (fp16) `+ residual` (fp16) order.
+template <int MT, int NT>
+__device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
+                                                      char* stg /* wave-private, 32 * (NT*64 + 16) bytes */) {
+    constexpr int WTN = NT * 32;
+    constexpr int PITCH = WTN * 2 + 16;
+    constexpr int CPR = WTN / 8;                 // 16-B chunks per row
+    constexpr int NQ = (32 * CPR + 63) / 64;
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int HW = p.rows_per_batch;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw0 + i * 32 + frow;
+        const int mc = m < p.M ? m : p.M - 1;
+        const int b = (HW > 0) ? mc / HW : 0;
+        // this lane's row: output / residual pixel index (shared with the other lanes by shuffle below)
+        int opix = mc, rpix = mc;
+        if (p.omode == 1 || p.rmode == 1) {
+            const int pp = padded_pix(mc, HW, p.W, p.H);
+            if (p.omode == 1) opix = pp;
+            if (p.rmode == 1) rpix = pp;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = j * 32 + 8 * g + 4 * fhi;
+                int n = nw0 + nl;
+                n = n < p.N ? n : p.N - 4;          // clamp (values unused beyond N)
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * p.out_scale;
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.temb) {
+                    const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+                    v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+                }
+                half4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                *reinterpret_cast<half4_t*>(stg + frow * PITCH + nl * 2) = o;
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = lane + 64 * q;
+            const int r = c / CPR, cc = c - r * CPR;
+            const int op = __shfl(opix, r), rp = __shfl(rpix, r);        // row r's pixel indices (lane r holds row r)
+            const int mm = mw0 + i * 32 + r, n = nw0 + cc * 8;
+            if (c < 32 * CPR && mm < p.M && n < p.N) {
+                half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
+                if (p.resid) {
+                    const half8_t rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
+                }
+                *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
+            }
+        }
+    }
+}
+
+// GEGLU through LDS: value tile j and gate tile j+1 of a wave hold the same 32 features; the product
+// v * gelu(g) is staged as [32 rows][NT/2*32 features] and written as row segments (16 B per lane).
+template <int MT, int NT>
+__device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
+                                                            char* stg) {
+    constexpr int WTF = (NT / 2) * 32;            // output features per wave
+    constexpr int PITCH = WTF * 2 + 16;
+    constexpr int CPR = WTF / 8;
+    constexpr int NQ = (32 * CPR + 63) / 64;
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int f0 = (nw0 >> 6) * 32;               // packed column -> feature (nw0 is a multiple of 64)
+    const int NF = p.N >> 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; j += 2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int pc = nw0 + j * 32 + 8 * g + 4 * fhi;          // packed value column
+                pc = pc < p.N ? pc : p.N - 64;
+                float v[4], gt[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
+                    const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+                half4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (half_t)(v[k] * gelu_erf_f(gt[k]));
+                *reinterpret_cast<half4_t*>(stg + frow * PITCH + ((j >> 1) * 32 + 8 * g + 4 * fhi) * 2) = o;
+            }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = lane + 64 * q;
+            const int r = c / CPR, cc = c - r * CPR;
+            const int mm = mw0 + i * 32 + r, f = f0 + cc * 8;
+            if (c < 32 * CPR && mm < p.M && f < NF)
+                *reinterpret_cast<half8_t*>(p.out + (long)mm * p.old + f) = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
+        }
+    }
+}
+
 // GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
@@ -386,6 +500,17 @@ igemm_kernel(const IGemmArgs p) {
                 for (int r = 0; r < 16; ++r) ws[(long)((i * NT + j) * 16 + r) * NTHR] = acc[i][j][r];
         return;
     }
+    if (p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
+        // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
+        igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)));
+        return;
+    }
+    if constexpr (NT % 2 == 0) {
+        if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
+            igemm_epilogue_geglu_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)));
+            return;
+        }
+    }
     igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
 }
 
@@ -428,6 +553,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
+static int g_staged_epi = 1;
+extern "C" void cfgpp_igemm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 : 0; }
 static int g_big_tiles = 1;
 extern "C" void cfgpp_igemm_set_big_tiles(int on) { g_big_tiles = on ? 1 : 0; }
 static int g_dbg = 0;
@@ -450,7 +577,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
-    a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.dbg = g_dbg;
+    a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.dbg = g_dbg; a.staged_epi = g_staged_epi;
     // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
     // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
     // finishes them.  S is chosen so that T*S fills the resident slots once or twice.

@@ -174,6 +174,7 @@ void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256
 void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
 void cfgpp_igemm_set_debug(int flags);    /* benchmark ablation: bit0 skip tile loads, bit1 skip MFMA */
 void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x320 tiles (default) */
+void cfgpp_igemm_set_staged_epilogue(int on); /* 1 = LDS-transposed row-coalesced store epilogue (default) */
 void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */
 
 #ifdef __cplusplus
