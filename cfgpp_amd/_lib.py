@@ -60,7 +60,9 @@ PROTOTYPES = {
     "cfgpp_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),
     "cfgpp_vae_finalize": (_I, [_P]),
     "cfgpp_vae_decode": (_I, [_P, _P, _P, _I, _P]),
+    "cfgpp_vae_encode": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "cfgpp_vae_flops": (C.c_double, [_P, _I]),
+    "cfgpp_vae_encode_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_device_bytes": (C.c_double, [_P]),
     "cfgpp_op_softmax_rows": (_I, [_P, _L, _I, _P]),
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
@@ -68,6 +70,7 @@ PROTOTYPES = {
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_vae_posterior": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "cfgpp_op_conv_out": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_sinusoid": (_I, [_P, _F, _P, _I, _I, _I, _I, _P]),
     "cfgpp_op_skinny_gemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -193,9 +193,9 @@ struct Plan {
 
     // conv3x3 on padded NHWC.  amode 1 normal, 2 stride-2 (src is 2H x 2W), 3 upsample (src is H/2 x W/2)
     void conv3x3(const Tensor& src, const Tensor& dst, const half_t* w, const float* bias, int amode,
-                 const float* temb, int temb_ld, const Tensor* resid) {
+                 const float* temb, int temb_ld, const Tensor* resid, int ashift = 0) {
         IGemmArgs a = base_args();
-        a.a0 = src.p; a.C0 = src.C; a.taps = 9; a.amode = amode; a.H = dst.H; a.W = dst.W;
+        a.a0 = src.p; a.C0 = src.C; a.taps = 9; a.amode = amode; a.ashift = ashift; a.H = dst.H; a.W = dst.W;
         a.w = w; a.N = dst.C; a.K = 9 * src.C; a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
         a.rows_per_batch = dst.H * dst.W;
         if (resid) { a.resid = resid->p; a.rmode = 1; a.rld = resid->C; }

@@ -16,6 +16,7 @@ struct IGemmArgs {
     int taps;          // 1 (linear / 1x1) or 9 (3x3, pad 1)
     int amode;         // 0 linear rows, 1 padded NHWC, 2 padded stride-2, 3 padded nearest-2x upsample
     int H, W;          // OUTPUT spatial size (amode >= 1): rows m enumerate (n, y, x)
+    int ashift;        // amode 2 only: 0 = pad 1 (UNet downsample), 1 = pad (0,1,0,1) (VAE encoder downsample)
     // ---- B operand: weights [N][K] fp16, K = taps*(C0+C1), k = tap*Cin + c ----
     const half_t* w;
     int M, N, K;

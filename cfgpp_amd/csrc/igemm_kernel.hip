@@ -307,7 +307,7 @@ igemm_kernel(const IGemmArgs p) {
         else if constexpr (AMODE == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
         else if constexpr (AMODE == 2) {
             const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
-            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1) * (2 * p.W + 2) + 2 * x + 1;
+            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1 + p.ashift) * (2 * p.W + 2) + 2 * x + 1 + p.ashift;
         } else {
             const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
             a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap

@@ -213,7 +213,48 @@ __global__ void f16_to_f32_rows_kernel(const half_t* __restrict__ in, float* __r
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------
+// AutoencoderKL posterior (diffusers DiagonalGaussianDistribution, reached from
+// latent_diffusion.py:117-121 / latent_sdxl.py:150-153):  moments = quant_conv(conv_out) (1x1, 8->8),
+// mean | logvar = chunk(moments), logvar clamped to [-30, 20], z = (mean + exp(logvar/2) * noise) * scale.
+// noise == null gives the posterior mean.  conv_out / quant_conv outputs are rounded to fp16 like the
+// reference's fp16 VAE does; the arithmetic itself is fp32.
+__global__ void __launch_bounds__(256)
+vae_posterior_kernel(const float* __restrict__ co, const float* __restrict__ qw, const float* __restrict__ qb,
+                     const float* __restrict__ noise, float* __restrict__ z, float* __restrict__ moments,
+                     int B, int HW, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (long)b * HW);
+    float x[8], m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)(half_t)co[((long)b * 8 + j) * HW + p];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float acc = qb[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += qw[o * 8 + j] * x[j];
+        m[o] = (float)(half_t)acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float lv = fminf(fmaxf(m[4 + c], -30.f), 20.f);
+        const float n = noise ? noise[((long)b * 4 + c) * HW + p] : 0.f;
+        z[((long)b * 4 + c) * HW + p] = (m[c] + __expf(0.5f * lv) * n) * scale;
+        if (moments) { moments[((long)b * 8 + c) * HW + p] = m[c]; moments[((long)b * 8 + 4 + c) * HW + p] = lv; }
+    }
+}
+
 extern "C" {
+
+int cfgpp_op_vae_posterior(const float* conv_out, const float* qw, const float* qb, const float* noise, float* z,
+                           float* moments, int B, int HW, float scale, void* stream) {
+    CFGPP_REQUIRE(conv_out && qw && qb && z && B > 0 && HW > 0, "vae_posterior: bad args");
+    hipLaunchKernelGGL(vae_posterior_kernel, dim3(cdiv((long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, conv_out, qw, qb, noise, z, moments, B, HW, scale);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                         int R, int zB, int Cin, int H, int W, int Cout, const float* pre_w, const float* pre_b,
@@ -237,12 +278,15 @@ int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, co
 
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                       int R, int H, int W, int C, int Cout, void* stream) {
-    CFGPP_REQUIRE(Cout >= 1 && Cout <= 4 && C % 8 == 0, "conv_out: Cout=%d C=%d", Cout, C);
+    CFGPP_REQUIRE(Cout >= 1 && Cout <= 8 && C % 8 == 0, "conv_out: Cout=%d C=%d", Cout, C);
     CFGPP_REQUIRE(x && out && w, "conv_out: null pointer");
     const long total = (long)R * H * W;
     dim3 grid(cdiv(total, 4));
     hipStream_t s = (hipStream_t)stream;
-    if (out_is_half)
+    if (Cout > 4) {       // VAE encoder moments (8 channels); weights must hold 8 output rows
+        CFGPP_REQUIRE(!out_is_half, "conv_out: 8-channel output is fp32 only");
+        hipLaunchKernelGGL((conv_out_kernel<8, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+    } else if (out_is_half)
         hipLaunchKernelGGL((conv_out_kernel<4, half_t>), grid, dim3(256), 0, s, (const half_t*)x, (half_t*)out, (const half_t*)w, bias, R, H, W, C, Cout);
     else
         hipLaunchKernelGGL((conv_out_kernel<4, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout);

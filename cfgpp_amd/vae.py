@@ -1,14 +1,14 @@
 """AutoencoderKL decode / encode.
 
-``HipVAE``   - the DECODER on the hand-written HIP kernels (``csrc/vae.hip`` behind the C ABI:
-               implicit-GEMM convs incl. fused upsample, GroupNorm+SiLU, GEMM-softmax-GEMM mid-block
-               attention).  This is what ``solver.decode()`` runs on the GPU and what the benchmark times.
+``HipVAE``   - decoder AND encoder on the hand-written HIP kernels (``csrc/vae.hip`` behind the C ABI:
+               implicit-GEMM convs incl. fused upsample / asymmetric stride-2 downsample, GroupNorm+SiLU,
+               GEMM-softmax-GEMM mid-block attention, quant_conv + posterior kernel).  This is what
+               ``solver.decode()`` / ``solver.encode()`` run on the GPU and what the benchmark times.
 ``TorchVAE`` - the same diffusers-0.27.1 AutoencoderKL architecture (SD1.5 ``vae`` /
                ``madebyollin/sdxl-vae-fp16-fix``: block_out_channels (128,256,512,512), 2 layers per
-               block, 4 latent channels) restated functionally on torch ops.  Used (a) on the CPU in
-               fp32 as the parity reference of ``HipVAE`` and in the CPU baseline, (b) for ``encode``
-               (image -> latent, only the inversion/edit solvers need it; once per image, still
-               torch-ROCm - the next thing to move).
+               block, 4 latent channels) restated functionally on torch ops.  Used on the CPU in
+               fp32 as the parity reference of ``HipVAE`` (tests) and in the CPU baseline; never on
+               the product path.
 Weights: seeded synthetic in exact diffusers shapes / key names (no checkpoints offline).
 
 Reference call sites: latent_diffusion.py:117-129 (scale 0.18215),
@@ -186,10 +186,11 @@ class TorchVAE:
 
 
 class HipVAE:
-    """VAE whose ``decode`` runs on libcfgpp_hip.so (no MIOpen, no torch conv).  ``encode`` delegates to a
-    lazily built :class:`TorchVAE` with the same weights."""
+    """VAE whose ``decode`` and ``encode`` run on libcfgpp_hip.so (no MIOpen, no torch conv).
+    ``with_encoder=False`` skips loading the encoder weights (text-to-image solvers never encode)."""
 
-    def __init__(self, scaling_factor: float, latent_hw, max_batch: int = 1, device=None, state_dict=None, seed: int = 0):
+    def __init__(self, scaling_factor: float, latent_hw, max_batch: int = 1, device=None, state_dict=None, seed: int = 0,
+                 with_encoder: bool = True):
         import ctypes as C
 
         from . import _lib
@@ -207,7 +208,7 @@ class HipVAE:
         if not self._h:
             raise CfgppError("cfgpp_vae_create failed: " + _lib.last_error())
         for k, v in self._sd.items():
-            if not (k.startswith("decoder.") or k.startswith("post_quant_conv.")):
+            if not with_encoder and (k.startswith("encoder.") or k.startswith("quant_conv.")):
                 continue
             t = v.detach().cpu().contiguous()
             dt = 1 if t.dtype == torch.float16 else 0
@@ -216,7 +217,7 @@ class HipVAE:
             shape = (C.c_long * t.dim())(*t.shape)
             check(self.lib.cfgpp_vae_load_tensor(self._h, k.encode(), t.data_ptr(), dt, shape, t.dim()), f"cfgpp_vae_load_tensor({k})")
         check(self.lib.cfgpp_vae_finalize(self._h), "cfgpp_vae_finalize")
-        self._torch = None
+        self.with_encoder = bool(with_encoder)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -239,10 +240,30 @@ class HipVAE:
         check(self.lib.cfgpp_vae_decode(self._h, z.data_ptr(), img.data_ptr(), B, torch.cuda.current_stream().cuda_stream), "cfgpp_vae_decode")
         return img
 
-    def encode(self, x, sample: bool = True, generator=None):
-        if self._torch is None:
-            self._torch = TorchVAE(self.scaling_factor, device=self.device, state_dict=self._sd)
-        return self._torch.encode(x, sample=sample, generator=generator)
+    def encode(self, x, sample: bool = True, generator=None, noise=None, return_moments: bool = False):
+        """x [B,3,8h,8w] in [-1,1] -> latent [B,4,h,w] fp32 = posterior sample * scaling_factor
+        (reference: latent_diffusion.py:117-121).  The posterior noise is drawn on the HOST (``generator`` or the
+        global CPU RNG, like the reference's initial latent) so runs are reproducible across devices; pass
+        ``noise`` to pin it, ``sample=False`` for the posterior mean."""
+        from ._lib import CfgppError, check
+        if not self.with_encoder:
+            raise CfgppError("HipVAE.encode: engine was built with with_encoder=False")
+        img = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B = int(img.shape[0])
+        if tuple(img.shape[1:]) != (3, 8 * self.h, 8 * self.w) or B > self.max_batch:
+            raise CfgppError(f"HipVAE.encode: image {tuple(img.shape)} does not fit engine [<= {self.max_batch}, 3, {8 * self.h}, {8 * self.w}]")
+        if sample and noise is None:
+            noise = torch.randn((B, 4, self.h, self.w), generator=generator)
+        nz = None if (not sample or noise is None) else noise.to(device=self.device, dtype=torch.float32).contiguous()
+        z = torch.empty((B, 4, self.h, self.w), dtype=torch.float32, device=self.device)
+        mom = torch.empty((B, 8, self.h, self.w), dtype=torch.float32, device=self.device) if return_moments else None
+        check(self.lib.cfgpp_vae_encode(self._h, img.data_ptr(), None if nz is None else nz.data_ptr(), z.data_ptr(),
+                                        None if mom is None else mom.data_ptr(), B, torch.cuda.current_stream().cuda_stream),
+              "cfgpp_vae_encode")
+        return (z, mom) if return_moments else z
+
+    def encode_flops(self, B: int) -> float:
+        return float(self.lib.cfgpp_vae_encode_flops(self._h, int(B)))
 
     def flops(self, B: int) -> float:
         return float(self.lib.cfgpp_vae_flops(self._h, int(B)))

@@ -132,7 +132,13 @@ void cfgpp_vae_destroy(cfgpp_vae* v);
 int cfgpp_vae_load_tensor(cfgpp_vae* v, const char* key, const void* host, int dtype, const long* shape, int ndim);
 int cfgpp_vae_finalize(cfgpp_vae* v);
 int cfgpp_vae_decode(cfgpp_vae* v, const void* z, void* img, int B, void* stream);
+/* Encoder (replaces `self.vae.encode(x).latent_dist.sample() * scale`, latent_diffusion.py:117-121,
+ * latent_sdxl.py:150-153); available when every encoder.* and quant_conv.* tensor was loaded.
+ * img [B][3][8h][8w] f32, noise [B][4][h][w] f32 or NULL (posterior mean), z [B][4][h][w] f32,
+ * moments [B][8][h][w] f32 or NULL (mean | logvar clamped to [-30, 20]). */
+int cfgpp_vae_encode(cfgpp_vae* v, const void* img, const void* noise, void* z, void* moments, int B, void* stream);
 double cfgpp_vae_flops(cfgpp_vae* v, int B);
+double cfgpp_vae_encode_flops(cfgpp_vae* v, int B);
 double cfgpp_vae_device_bytes(cfgpp_vae* v);
 
 /* ---- single ops, exposed for parity tests and micro-benchmarks ------------- */
@@ -150,6 +156,9 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                      int R, int zB, int Cin, int H, int W, int Cout, void* stream);
+/* quant_conv (1x1, 8->8) + DiagonalGaussian posterior on the encoder's 8-channel conv_out (fp32 NCHW). */
+int cfgpp_op_vae_posterior(const float* conv_out, const float* qw, const float* qb, const float* noise, float* z,
+                           float* moments, int B, int HW, float scale, void* stream);
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                       int R, int H, int W, int C, int Cout, void* stream);
 int cfgpp_op_sinusoid(const float* vals, float scalar, float* out, int count, int dim, int out_ld, int out_off,

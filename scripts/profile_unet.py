@@ -29,3 +29,9 @@ tot = sum(a[1] for a in agg.values()) / N
 print(f"# {name} rows={rows} staging={'glds' if staging else 'reg'} total {tot/1e3:.2f} ms/forward")
 for (kind, desc), (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{us/N/1e3:8.3f} ms  {100*us/N/tot:5.1f}%  x{cnt//N:<3d} {gf/us*1e3 if us else 0:7.1f} TF/s  [{kind}] {desc}")
+# wall clock of back-to-back forwards (launch gaps included) vs the sum of per-launch times above
+torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): eng.predict(z, 500.0)
+e1.record(); torch.cuda.synchronize()
+print(f"# wall {e0.elapsed_time(e1)/10:.2f} ms/forward (10 back-to-back predict() calls)")
