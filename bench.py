@@ -190,10 +190,10 @@ def main():
     cond = D.broadcast_conditioning(payload, shapes, dev)
     lo, hi = D.shard_range(total, rank, world)
     seeds = [42 + i for i in range(lo, hi)]
-    src_latent = None
-    if "inversion" in name:
+    src_img = None
+    if "inversion" in name:      # seeded synthetic source image in [-1, 1]; VAE encode (HIP) is inside the timed job
         g = torch.Generator().manual_seed(7)
-        src_latent = (torch.randn((B, 4, img // 8, img // 8), generator=g) * cfg.vae_scale * 5).to(dev)
+        src_img = (torch.rand((B, 3, img, img), generator=g) * 2 - 1).to(dev)
 
     def one_job():
         if kind == "sd":
@@ -201,7 +201,7 @@ def main():
         pe = (cond[0], cond[1][lo:hi].contiguous(), cond[2], cond[3][lo:hi].contiguous())
         if "inversion" in name:
             pe = (pe[0], pe[1], pe[1], pe[2], pe[3], pe[3])
-            return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_latent=src_latent)
+            return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_img=src_img)
         return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), seeds=seeds)
 
     for i in range(args.warmup):
@@ -230,7 +230,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
         "config": {"workload": desc, "per_gpu_batch": B, "global_batch": total, "nfe": nfe, "lambda": lam,
-                   "unet_batch_rows": rows, "includes": "UNet + fused CFG++ step x NFE, VAE decode (HIP kernels), D2H copy",
+                   "unet_batch_rows": rows, "includes": ("VAE encode (HIP kernels), " if "inversion" in name else "") + "UNet + fused CFG++ step x NFE, VAE decode (HIP kernels), D2H copy",
                    "weights": "seeded synthetic, exact diffusers shapes", "flops_per_image": flops_per_image,
                    "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
     }

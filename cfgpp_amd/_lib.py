@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcfgpp_hip.so")
+LIB_PATH = os.environ.get("CFGPP_LIB") or os.path.join(HERE, "libcfgpp_hip.so")   # CFGPP_LIB: A/B a second build (development only)
 
 
 class CfgppError(RuntimeError):
@@ -83,6 +83,7 @@ PROTOTYPES = {
     "cfgpp_igemm_set_big_tiles": (None, [_I]),
     "cfgpp_igemm_set_debug": (None, [_I]),
     "cfgpp_igemm_set_tail_split": (None, [_I]),
+    "cfgpp_igemm_set_autotune": (None, [_I]),
 }
 
 _lib = None

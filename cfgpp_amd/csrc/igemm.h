@@ -42,8 +42,11 @@ struct IGemmArgs {
     int n_main;               // tiles [0, n_main) are computed whole by one block each
     int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
     float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
+    int cfg_hint;             // 0 = heuristic; 1/4/5/6 = tile config pinned by the engine's in-situ tuning pass
+    int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
     int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
     int dbg;                  // ablation (benchmarks only): bit0 = no tile loads after the first, bit1 = no MFMA
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);
+int igemm_autotune_enabled();

@@ -22,6 +22,9 @@
 //     one XCD's L2.
 // Epilogues: bias, per-batch time-embedding add, residual add, GEGLU, and the
 // head-major Q / K / V^T scatter the attention kernel consumes.
+#include <map>
+#include <tuple>
+#include <type_traits>
 #include "igemm.h"
 
 namespace {
@@ -255,7 +258,7 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 // AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
     constexpr int NTHR = 64 * WM * WN;
@@ -422,17 +425,151 @@ igemm_kernel(const IGemmArgs p) {
     const int b_rd = (wn * WTN + frow) * 128;
 
     if constexpr (GLDS) {
-        dma_tile(kt_begin, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- DMA path: the next tile's global->LDS pieces are issued BETWEEN the MFMAs of this tile ----
+        // Issued back to back at the top of the tile, the (A_CH + B_CH) LDS-DMA instructions of the two waves
+        // that share a SIMD cost ~100-185 cycles of issue each while neither wave feeds the matrix pipe (ISA +
+        // guide "LDS-DMA piece issue cost").  Spread one by one over the first half of the tile's MFMAs they
+        // cost ~60 cycles each and the partner wave's MFMAs cover them; the second half of the tile is the
+        // landing time before the end-of-tile vmcnt(0) + barrier.
+        constexpr int NP = A_CH + B_CH;               // DMA pieces per wave per K-tile
+        constexpr int NM = 4 * MT * NT;               // MFMAs per wave per K-tile
+        constexpr bool ILV = (WM * WN >= 8);          // 4-wave tiles overlap through co-resident blocks instead
+        constexpr int SPAN = ILV ? (NM * 5) / 8 : 0;  // pieces go out during the first 5/8 of the MFMAs
+        // NST-stage LDS ring: tile kt is computed from stage (kt - kt_begin) % NST while tiles kt+1 .. kt+NST-1
+        // are in flight / landed; a tile has NST-1 tile times to arrive (memory latency under load is of the
+        // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
+        const int nk = kt_end - kt_begin;
+#pragma unroll
+        for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
+        if (NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        auto tile_body = [&](int kt, auto with_dma) {
+            constexpr bool DMA = decltype(with_dma)::value;
+            const int cur = (kt - kt_begin) % NST;
+            const char* As = smem + cur * STAGE_BYTES;
+            const char* Bs = As + BM * 128;
+            // per-tile scalars of the NEXT tile's gather
+            const half_t* src = p.a0; int cs = 0, Cs = p.C0, dpix = 0, dy = 0, dx = 0;
+            char* Asn = smem + ((kt - kt_begin + NST - 1) % NST) * STAGE_BYTES;
+            char* Bsn = Asn + BM * 128;
+            if constexpr (DMA) {
+                const int ktn = kt + NST - 1;
+                const int tap = ktn / tiles_per_tap;
+                const int cc = (ktn - tap * tiles_per_tap) << 6;
+                const bool s0 = cc < p.C0;
+                src = s0 ? p.a0 : p.a1;
+                cs = s0 ? cc : cc - p.C0; Cs = s0 ? p.C0 : p.C1;
+                if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+                if constexpr (AMODE == 1) dpix = dy * (p.W + 2) + dx;
+                else if constexpr (AMODE == 2) dpix = dy * (2 * p.W + 2) + dx;
+            }
+            auto piece = [&](int q) {
+                if (q < A_CH) {
+                    const int j = q;
+                    int pix;
+                    if constexpr (AMODE == 3) {
+                        const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                        const int Hs = p.H >> 1, Ws = p.W >> 1;
+                        pix = (b * (Hs + 2) + ((y + dy) >> 1) + 1) * (Ws + 2) + ((x + dx) >> 1) + 1;
+                    } else {
+                        pix = a_pix[j] + dpix;
+                    }
+                    const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(Asn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+                } else {
+                    const int j = q - A_CH;
+                    const half_t* g = b_ptr[j] + ((long)(kt + NST - 1) << 6);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(Bsn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+                }
+            };
+            int issued = 0, done = 0;                 // compile-time after unrolling
+            if constexpr (DMA && !ILV) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) piece(q);
+                issued = NP;
+            }
+            auto after_mfma = [&]() {
+                ++done;
+                if constexpr (DMA && ILV) {
+                    if (issued < NP && done * NP >= (issued + 1) * SPAN) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(issued); ++issued;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            if constexpr (MT * NT <= 8) {
+                // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+                half8_t xa[2][MT], wb[2][NT];
+                {
+                    const int coff = ((0 | fhi) ^ fsw) << 4;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) {
+                        const int coff = ((((ks + 1) << 1) | fhi) ^ fsw) << 4;
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) xa[(ks + 1) & 1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) wb[(ks + 1) & 1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][j], xa[ks & 1][i], acc[i][j], 0, 0, 0);
+                            after_mfma();
+                        }
+                }
+            } else {
+                // 10 accumulator tiles per wave (256x320): no room for a second fragment set; 10 MFMAs per k-step
+                // (320 cycles) give the partner wave on the SIMD time to cover the LDS latency instead
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+                    half8_t xa[MT], wb[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                            after_mfma();
+                        }
+                    __builtin_amdgcn_sched_barrier(0);      // keep one fragment set live: no hoisting of the next k-step's reads
+                }
+            }
+            if constexpr (DMA) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) if (q >= issued) piece(q);      // (none when SPAN <= NM)
+                // tile kt+1 has landed once at most the (NST-2) younger tiles' pieces are outstanding
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        };
+        int kt = kt_begin;
+        for (; kt + NST - 1 < kt_end; ++kt) tile_body(kt, std::true_type{});
+        for (; kt < kt_end; ++kt) tile_body(kt, std::false_type{});
     } else {
         load_tile(kt_begin);
         store_tile(0);
-    }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         if (kt + 1 < kt_end) {
-            if constexpr (GLDS) dma_tile(kt + 1, cur ^ 1); else load_tile(kt + 1);
+            load_tile(kt + 1);
         }
         const char* As = smem + cur * STAGE_BYTES;
         const char* Bs = As + BM * 128;
@@ -480,12 +617,10 @@ igemm_kernel(const IGemmArgs p) {
                 __builtin_amdgcn_sched_barrier(0);      // keep one fragment set live: no hoisting of the next k-step's reads
             }
         }
-        if constexpr (GLDS) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next tile has landed in the other stage
-        } else {
-            if (kt + 1 < kt_end) store_tile(cur ^ 1);
-        }
+        if (kt + 1 < kt_end) store_tile(cur ^ 1);
         __syncthreads();
+    }
+
     }
 
     const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
@@ -561,14 +696,14 @@ static int g_dbg = 0;
 extern "C" void cfgpp_igemm_set_debug(int flags) { g_dbg = flags; }   // ablation hooks are compiled out of the product kernel
 static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = NST * (BM + BN) * 128;
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -581,7 +716,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
     // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
     // finishes them.  S is chosen so that T*S fills the resident slots once or twice.
-    if (g_tail_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
+    if (g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
         int S = (slots + T - 1) / T;                       // one full round
         if (KT / S < 12) S = KT / 12;
         if (S > 16) S = 16;
@@ -598,13 +733,13 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0>(a, stream);
-        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1>(a, stream);
-        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2>(a, stream);
-        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3>(a, stream);
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
+        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST>(a, stream);
+        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST>(a, stream);
+        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST>(a, stream);
         default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
     }
 }
@@ -619,7 +754,33 @@ extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
 extern "C" void cfgpp_igemm_set_staging(int glds) { g_staging = glds ? 1 : 0; }
 extern "C" void cfgpp_igemm_set_tail_split(int on) { g_tail_split = on ? 1 : 0; }
 
-int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
+static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
+    bool glds = g_staging != 0;
+    if (cfg > 10) { cfg -= 10; glds = false; }
+    switch (cfg) {
+        case 1: return glds ? launch_cfg<2, 2, 64, 64, true>(a, stream) : launch_cfg<2, 2, 64, 64, false>(a, stream);
+        case 2: return glds ? launch_cfg<4, 1, 64, 64, true>(a, stream) : launch_cfg<4, 1, 64, 64, false>(a, stream);
+        case 3: return glds ? launch_cfg<2, 2, 32, 32, true>(a, stream) : launch_cfg<2, 2, 32, 32, false>(a, stream);
+        // 8-wave, one-workgroup-per-CU tiles: fewer tile bytes per FLOP through the CU's memory->LDS path
+        case 4: return launch_cfg<2, 4, 128, 64, true>(a, stream);     // 256 x 256
+        case 5: return launch_cfg<4, 2, 64, 160, true>(a, stream);     // 256 x 320 (every SD/SDXL channel count is k*320)
+        case 6: return launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128
+        default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
+    }
+}
+
+// ---- in-situ tile tuning -------------------------------------------------------------------------
+// The engines time every igemm launch of their plan in place (HIP events between the launches of a real
+// forward) once per candidate tile config and pin the fastest per launch through IGemmArgs::cfg_hint
+// (engine_base.h, tune_plan).  Every non-split config runs the K loop in the same order, so the RESULT does
+// not depend on the choice (bit-identical); K-split launches (different summation order) stay rule-based.
+static int g_autotune = 1;
+extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
+int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_staging != 0; }
+
+int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
+    IGemmArgs a = a_in;
+    a.allow_split = 1;
     const int Cin = a.C0 + a.C1;
     CFGPP_REQUIRE(a.C0 > 0 && a.C0 % 64 == 0 && a.C1 % 64 == 0, "igemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
     CFGPP_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps=%d", a.taps);
@@ -651,16 +812,13 @@ int igemm_launch(const IGemmArgs& a, hipStream_t stream) {
         else cfg = 3;
         if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
     }
-    bool glds = g_staging != 0;
-    if (cfg > 10) { cfg -= 10; glds = false; }
-    switch (cfg) {
-        case 1: return glds ? launch_cfg<2, 2, 64, 64, true>(a, stream) : launch_cfg<2, 2, 64, 64, false>(a, stream);
-        case 2: return glds ? launch_cfg<4, 1, 64, 64, true>(a, stream) : launch_cfg<4, 1, 64, 64, false>(a, stream);
-        case 3: return glds ? launch_cfg<2, 2, 32, 32, true>(a, stream) : launch_cfg<2, 2, 32, 32, false>(a, stream);
-        // 8-wave, one-workgroup-per-CU tiles: fewer tile bytes per FLOP through the CU's memory->LDS path
-        case 4: return launch_cfg<2, 4, 128, 64, true>(a, stream);     // 256 x 256
-        case 5: return launch_cfg<4, 2, 64, 160, true>(a, stream);     // 256 x 320 (every SD/SDXL channel count is k*320)
-        case 6: return launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128
-        default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
+    if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0) {
+        const int KT = a.K >> 6;
+        const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
+        const int h = a.cfg_hint;
+        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 5 && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
+    return launch_config(cfg, a, stream);
 }

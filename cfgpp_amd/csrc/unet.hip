@@ -500,6 +500,9 @@ int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
     CFGPP_REQUIRE(z && eps_out && z_rows > 0 && rows > 0 && rows <= u->cfg.max_rows, "forward: bad args (rows=%d max=%d)", rows, u->cfg.max_rows);
     CFGPP_REQUIRE(rows == u->ctx_rows, "forward: rows=%d but context was set for %d rows", rows, u->ctx_rows);
     u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
+    if (u->tuned_rows != rows && igemm_autotune_enabled()) {      // first forward at this batch: in-situ tile tuning
+        int e = u->tune_plan((hipStream_t)stream, rows); if (e) return e;
+    }
     for (auto& op : u->plan) { int e = op((hipStream_t)stream, rows); if (e) return e; }
     return 0;
 }

@@ -359,6 +359,7 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
 int cfgpp_vae_decode(cfgpp_vae* v, const void* z, void* img, int B, void* stream) {
     CFGPP_REQUIRE(v && v->finalized && z && img && B > 0 && B <= v->max_rows, "vae_decode: bad args (B=%d, max %d)", B, v ? v->max_rows : 0);
     v->in_z = z; v->out_img = img;
+    if (v->tuned_rows != B && igemm_autotune_enabled()) { int e = v->tune_plan((hipStream_t)stream, B); if (e) return e; }
     for (auto& op : v->plan) { int e = op((hipStream_t)stream, B); if (e) return e; }
     return 0;
 }

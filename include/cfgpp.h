@@ -181,6 +181,9 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128; 11..13 = register-staged 1..3 */
 void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
+/* 1 (default): the first launch of every GEMM shape times the candidate tile configs and keeps the fastest
+ * (results are bit-identical across candidates; K-split launches are rule-based). 0: fixed heuristic. */
+void cfgpp_igemm_set_autotune(int on);
 void cfgpp_igemm_set_debug(int flags);    /* benchmark ablation: bit0 skip tile loads, bit1 skip MFMA */
 void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x320 tiles (default) */
 void cfgpp_igemm_set_staged_epilogue(int on); /* 1 = LDS-transposed row-coalesced store epilogue (default) */

@@ -33,10 +33,12 @@ for name, kind, R, hw, Cin, N in SHAPES:
         w = torch.randn(N, K, device="cuda", dtype=torch.float16) * K ** -0.5; o = torch.empty(M, N, device="cuda", dtype=torch.float16)
         fn = lambda: H.igemm(x, None, K, 0, 1, 0, 0, 0, w, M, N, out=o, omode=0, old=N)
     res = []
+    H.lib().cfgpp_igemm_force_config(1); fn(); ref = o.float().clone()
     for c in cfgs:
         H.lib().cfgpp_igemm_force_config(c)
         try:
-            dt = timeit(fn); res.append(f"cfg{c}:{2.0*M*N*K/dt/1e12:6.0f}")
+            dt = timeit(fn); bad = "" if float((o.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) else "!WRONG"
+            res.append(f"cfg{c}:{2.0*M*N*K/dt/1e12:6.0f}{bad}")
         except Exception as e: res.append(f"cfg{c}: ERR")
     H.lib().cfgpp_igemm_force_config(0)
     print(f"{name:18s} M={M:6d} N={N:5d} K={K:6d}  " + "  ".join(res), flush=True)

@@ -8,6 +8,7 @@ rows = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 hw = int(sys.argv[3]) if len(sys.argv) > 3 else None
 staging = int(os.environ.get("STAGING", "1"))
 _lib.load().cfgpp_igemm_set_staging(staging)
+_lib.load().cfgpp_igemm_set_autotune(int(os.environ.get("AUTOTUNE", "1")))
 eng = HipEngine(name, max_batch=rows // 2, latent_hw=(hw, hw) if hw else None)
 cfg = eng.cfg
 B = rows // 2
