@@ -109,6 +109,8 @@ def load():
             raise CfgppError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("CFGPP_AUTOTUNE", "1") == "0":      # e.g. under rocprofv3 --pmc: no timing passes
+        lib.cfgpp_igemm_set_autotune(0)
     _lib = lib
     return lib
 

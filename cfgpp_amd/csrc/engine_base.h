@@ -194,14 +194,14 @@ struct Builder {
         HostParam* p = get(key); if (!p) return nullptr;
         half_t* d = upload(p->h); drop(key); return d;
     }
-    // OIHW -> [O][kh*kw][I]
+    // OIHW -> [O][I/64][kh*kw][64]  (K order of the implicit GEMM: channel-block major, tap minor)
     half_t* conv3(const std::string& key) {
         HostParam* p = get(key); if (!p) return nullptr;
         const long O = p->shape[0], I = p->shape[1];
         std::vector<half_t> r((size_t)O * 9 * I);
         for (long o = 0; o < O; ++o)
             for (long i = 0; i < I; ++i)
-                for (int t = 0; t < 9; ++t) r[((size_t)o * 9 + t) * I + i] = p->h[((size_t)o * I + i) * 9 + t];
+                for (int t = 0; t < 9; ++t) r[(size_t)o * 9 * I + ((i >> 6) * 9 + t) * 64 + (i & 63)] = p->h[((size_t)o * I + i) * 9 + t];
         half_t* d = upload(r); drop(key); return d;
     }
     // concat rows of several [n_i][K] matrices

@@ -17,7 +17,9 @@ struct IGemmArgs {
     int amode;         // 0 linear rows, 1 padded NHWC, 2 padded stride-2, 3 padded nearest-2x upsample
     int H, W;          // OUTPUT spatial size (amode >= 1): rows m enumerate (n, y, x)
     int ashift;        // amode 2 only: 0 = pad 1 (UNet downsample), 1 = pad (0,1,0,1) (VAE encoder downsample)
-    // ---- B operand: weights [N][K] fp16, K = taps*(C0+C1), k = tap*Cin + c ----
+    // ---- B operand: weights [N][K] fp16, K = taps*(C0+C1).  K order is CHANNEL-BLOCK major, tap minor:
+    //      k = (cb*taps + tap)*64 + c  (cb = 64-channel block of the concatenated input).  The 9 taps of one
+    //      channel block are consecutive K-tiles, so their shifted re-reads of the same pixels hit L2.
     const half_t* w;
     int M, N, K;
     // ---- epilogue ----

@@ -290,6 +290,8 @@ igemm_kernel(const IGemmArgs p) {
         wg = p.n_main + b2 / p.ksplit;
         ksl = b2 - (b2 / p.ksplit) * p.ksplit;
     }
+    // (An N-major walk - weight tiles shared inside an XCD instead of activation rows - was measured: fewer
+    // fabric bytes on the weight-heavy levels but 0.3-1.6 % slower end to end, so the order stays M-major.)
     const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -300,7 +302,6 @@ igemm_kernel(const IGemmArgs p) {
     const int lrow = tid >> 3, lchunk = tid & 7;
     const int HW = p.rows_per_batch;
     const int Cin = p.C0 + p.C1;
-    const int tiles_per_tap = Cin >> 6;
     int a_pix[A_CH];
 #pragma unroll
     for (int j = 0; j < A_CH; ++j) {
@@ -340,8 +341,8 @@ igemm_kernel(const IGemmArgs p) {
     const int kt_end = is_tail ? (int)(((long)(ksl + 1) * KT_all) / p.ksplit) : KT_all;
 
     auto load_tile = [&](int kt) {
-        const int tap = kt / tiles_per_tap;
-        const int cc = (kt - tap * tiles_per_tap) << 6;
+        int tap = 0, cc = kt << 6;
+        if (p.taps == 9) { const int cb = kt / 9; tap = kt - cb * 9; cc = cb << 6; }
         const bool s0 = cc < p.C0;
         const half_t* src = s0 ? p.a0 : p.a1;
         const int cs = s0 ? cc : cc - p.C0, Cs = s0 ? p.C0 : p.C1;
@@ -368,8 +369,8 @@ igemm_kernel(const IGemmArgs p) {
     // DMA variant: same addresses, destination = wave-uniform LDS base (+ lane*16 added by hardware)
     const int wave_row0 = __builtin_amdgcn_readfirstlane(wid) * 8;
     auto dma_tile = [&](int kt, int stage) {
-        const int tap = kt / tiles_per_tap;
-        const int cc = (kt - tap * tiles_per_tap) << 6;
+        int tap = 0, cc = kt << 6;
+        if (p.taps == 9) { const int cb = kt / 9; tap = kt - cb * 9; cc = cb << 6; }
         const bool s0 = cc < p.C0;
         const half_t* src = s0 ? p.a0 : p.a1;
         const int cs = s0 ? cc : cc - p.C0, Cs = s0 ? p.C0 : p.C1;
@@ -455,8 +456,8 @@ igemm_kernel(const IGemmArgs p) {
             char* Bsn = Asn + BM * 128;
             if constexpr (DMA) {
                 const int ktn = kt + NST - 1;
-                const int tap = ktn / tiles_per_tap;
-                const int cc = (ktn - tap * tiles_per_tap) << 6;
+                int tap = 0, cc = ktn << 6;
+                if (p.taps == 9) { const int cb = ktn / 9; tap = ktn - cb * 9; cc = cb << 6; }
                 const bool s0 = cc < p.C0;
                 src = s0 ? p.a0 : p.a1;
                 cs = s0 ? cc : cc - p.C0; Cs = s0 ? p.C0 : p.C1;

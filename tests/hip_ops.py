@@ -52,9 +52,10 @@ def halo_is_zero(pn: torch.Tensor) -> bool:
 
 
 def pack_conv3(w_oihw: torch.Tensor) -> torch.Tensor:
-    """OIHW -> [O][9][I] fp16 (k = tap*Cin + c)."""
+    """OIHW -> [O][I/64][9][64] fp16 (k = (cb*9 + tap)*64 + c: channel-block major, tap minor)."""
     O, I, kh, kw = w_oihw.shape
-    return w_oihw.permute(0, 2, 3, 1).reshape(O, kh * kw * I).to(DEV, torch.float16).contiguous()
+    return (w_oihw.permute(0, 2, 3, 1).reshape(O, kh * kw, I // 64, 64).permute(0, 2, 1, 3)
+            .reshape(O, kh * kw * I).to(DEV, torch.float16).contiguous())
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor):
