@@ -100,6 +100,12 @@ class StableDiffusion:
         self.text_encoder = kwargs.get("text_encoder") or SyntheticTextEncoder(cfg.cross_attention_dim, None)
         self.vae = kwargs.get("vae")
         self._vae_kwargs = dict(seed=kwargs.get("vae_seed", 0))
+        vw = kwargs.get("vae_weights")                  # diffusers AutoencoderKL state dict, or a safetensors path
+        if vw is not None:
+            if isinstance(vw, str):
+                from .weights import load_safetensors_iter
+                vw = dict(load_safetensors_iter(vw))
+            self._vae_kwargs["state_dict"] = vw
 
     # ------------------------------------------------------------------ reference API
     def __call__(self, *args: Any, **kwargs: Any) -> Any:
