@@ -68,6 +68,7 @@ PROTOTYPES = {
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "cfgpp_op_attention_prepare_vt": (_I, [_P, _I, _I, _I, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_vae_posterior": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),

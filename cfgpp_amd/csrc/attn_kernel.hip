@@ -10,6 +10,13 @@
 //   * Online softmax entirely in registers (one __shfl_xor(…,32) for the row max); Q is pre-scaled by
 //     d^-1/2*log2(e) so scores feed v_exp_f32 directly; the O rescale is skipped (exactly) on tiles
 //     where no query's running max grows; key masking only on a partial last tile.
+//   * The loop is VALU-bound, not MFMA-bound, at small d (150 VALU vs 14 MFMA per 64-key tile at d = 40), so
+//     two thirds of the softmax VALU is moved into the MFMAs: (i) the accumulator of S^T is INITIALISED with
+//     -m (a persistent 16-register vector, rewritten only when a running max grows), so scores come out as
+//     s - m and feed v_exp_f32 without a subtract; (ii) when d is not a multiple of 32 the first padding row
+//     of V^T holds ONES (written once at engine build, cfgpp_op_attention_prepare_vt), so row d of O^T
+//     accumulates sum_k P[k][q] - the softmax denominator - inside the PV MFMAs (no v_add chain, and the
+//     denominator sums exactly the fp16 P values the numerator uses).
 //   * O^T += V^T P^T: the B operand (P^T) is exactly the lane's own 8 consecutive
 //     accumulator registers converted to fp16 (the MFMA k-slot <-> key assignment is
 //     free as long as A and B agree), the A operand is 2 x ds_read_b64 from V^T.
@@ -32,7 +39,7 @@ struct AttnArgs {
     float scale_log2e;    // d^-0.5 * log2(e)
 };
 
-template <int D16, int DT>
+template <int D16, int DT, bool ONES, int QT>
 __global__ void __launch_bounds__(256)
 attn_kernel(const AttnArgs a) {
     constexpr int DP = DT * 32;                  // padded head dim (row pitch of Q/K, rows of V^T)
@@ -43,30 +50,43 @@ attn_kernel(const AttnArgs a) {
     static_assert((64 * DP / 8) % 256 == 0, "tile/loader mismatch");
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages of (K tile | V^T tile)
 
+    // QT query sub-tiles of 32 per wave: every K / V^T fragment read from LDS feeds QT MFMAs.  Measured with
+    // QT = 2 (240-256 VGPRs, 2 waves/SIMD): +2 % at d = 40, -11 % at d = 64 (N = 4096), so QT = 1 ships.
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int q0 = blockIdx.x * (128 * QT) + wid * (32 * QT);
     const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
     const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
     const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
 
-    // Q^T fragments (B operand): lane = query q0+l31, 8 consecutive d at ks*16 + hi*8, pre-multiplied by
+    // Q^T fragments (B operand): lane = query q0+qt*32+l31, 8 consecutive d at ks*16 + hi*8, pre-multiplied by
     // d^-1/2 * log2(e) so that the scores come out of the MFMA ready for exp2.
-    half8_t qf[D16];
+    half8_t qf[QT][D16];
 #pragma unroll
-    for (int ks = 0; ks < D16; ++ks) {
-        const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
-    }
+        for (int ks = 0; ks < D16; ++ks) {
+            const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + qt * 32 + l31) * DP + ks * 16 + hi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
+        }
 
-    f32x16 oacc[DT];
+    f32x16 oacc[QT][DT];
+    // negm = -m_ref broadcast over the 16 accumulator registers (C operand of the first S^T MFMA);
+    // m_ref = 0 until the first tile (which always takes the "max grew" path) sets it.
+    f32x16 negm[QT];
+    float l_run[QT];                 // only used when !ONES
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
+    for (int qt = 0; qt < QT; ++qt) {
+        l_run[qt] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int r = 0; r < 16; ++r) negm[qt][r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qt][i][r] = 0.f;
+    }
 
     const int ntiles = (a.nk_valid + 63) >> 6;
     const int tail = a.nk_valid & 63;            // != 0: the last tile is partially masked
@@ -103,67 +123,76 @@ attn_kernel(const AttnArgs a) {
         const char* Ks = smem + (t & 1) * STAGE;
         const char* Vs = Ks + 64 * KPITCH;
 
-        // ---- S^T = K Q^T for two 32-key sub-tiles (scores already in the log2 domain) ----
-        f32x16 s[2];
+        // ---- S^T - m = K Q^T + (-m) for two 32-key sub-tiles (log2 domain) ----
+        f32x16 s[QT][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            {
-                const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 32 + l31) * KPITCH + (hi * 8) * 2);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], zero, 0, 0, 0);
-            }
 #pragma unroll
-            for (int ks = 1; ks < D16; ++ks) {
+            for (int ks = 0; ks < D16; ++ks) {
                 const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (kt * 32 + l31) * KPITCH + (ks * 16 + hi * 8) * 2);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kt], 0, 0, 0);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qt][ks], ks == 0 ? negm[qt] : s[qt][kt], 0, 0, 0);
             }
         }
         if (tail != 0 && t == ntiles - 1) {      // wave-uniform: mask keys >= nk_valid (cross-attention, 77 keys)
             const int kbase = t * 64 + 4 * hi;
 #pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+                        s[qt][kt][r] = key < a.nk_valid ? s[qt][kt][r] : -INFINITY;
+                    }
+        }
+        // ---- online softmax: per query = per lane column; keys across 32 registers and the two half-waves ----
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = s[qt][0][0];                  // tile max RELATIVE to m_ref
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qt][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (t == 0 || !__all(mx <= 0.f)) {       // some query's max grew (always on the first tile): re-reference (exact)
+                const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);         // O = 0 on the first tile: alpha irrelevant
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[qt][i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[qt][r] -= delta;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qt][kt][r] -= delta;
+            }
+            float psum = 0.f;
+#pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
-                    s[kt][r] = key < a.nk_valid ? s[kt][r] : -INFINITY;
+                    const float pv = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                    s[qt][kt][r] = pv;
+                    if constexpr (!ONES) psum += pv;
                 }
+            if constexpr (!ONES) l_run[qt] += psum;
         }
-        // ---- online softmax: per query = per lane column; keys across 32 registers and the two half-waves ----
-        float mx = s[0][0];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (!__all(mx <= m_run)) {                // some query's max grew: rescale (exact; skipped otherwise)
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_run);
-                s[kt][r] = pv;
-                psum += pv;
-            }
-        l_run += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                half8_t pf;
+                half8_t pf[QT];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kt][8 * tt + j];
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * tt + j];
                 // k-slot j = b*4 + r  <->  key = kt*32 + 8*(2*tt + b) + 4*hi + r
                 const int kcol0 = kt * 32 + 16 * tt + 4 * hi;
 #pragma unroll
@@ -174,7 +203,9 @@ attn_kernel(const AttnArgs a) {
                     half8_t vf;
                     vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                     vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        oacc[qt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qt], oacc[qt][i], 0, 0, 0);
                 }
             }
         // ---- stage tile t+1 (registers -> the other LDS stage), prefetch tile t+2 ----
@@ -184,33 +215,54 @@ attn_kernel(const AttnArgs a) {
     }
 
     // ---- finalize: O = O^T / l, store token-major ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < a.nq) {
-        const int b = bh / a.heads, head = bh - b * a.heads;
-        half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+    for (int qt = 0; qt < QT; ++qt) {
+        float l_tot;
+        if constexpr (ONES) {
+            // row d of O^T (the ones row of V^T) = sum_k P[k][q]: register (d%32 / 8) * 4 of tile d/32, half-wave 0
+            const int dr = a.d & 31;                                   // multiple of 8 by contract
+            float lv = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = i * 32 + 8 * g + 4 * hi;
-                if (dd < a.d) {
-                    half4_t o;
+            for (int g = 0; g < 4; ++g) if (dr == 8 * g) lv = oacc[qt][DT - 1][4 * g];
+            l_tot = __shfl(lv, l31);
+        } else {
+            l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+        }
+        const float inv_l = 1.0f / l_tot;
+        const int q = q0 + qt * 32 + l31;
+        if (q < a.nq) {
+            const int b = bh / a.heads, head = bh - b * a.heads;
+            half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[i][4 * g + k] * inv_l);
-                    *reinterpret_cast<half4_t*>(orow + dd) = o;
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dd = i * 32 + 8 * g + 4 * hi;
+                    if (dd < a.d) {
+                        half4_t o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[qt][i][4 * g + k] * inv_l);
+                        *reinterpret_cast<half4_t*>(orow + dd) = o;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int D16, int DT>
+// sets row d of every V^T matrix to 1.0 (see the kernel header); vt [BH][dp][tok_pad]
+__global__ void attn_ones_row_kernel(half_t* vt, int BH, int d, int dp, int tok_pad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)BH * tok_pad) return;
+    const long bh = i / tok_pad, k = i - bh * tok_pad;
+    vt[(bh * dp + d) * tok_pad + k] = (half_t)1.0f;
+}
+
+template <int D16, int DT, bool ONES, int QT>
 int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int DP = DT * 32;
     constexpr int smem = 2 * (64 * (DP * 2 + 16) + DP * (64 * 2 + 16));
     static bool attr_set = false;
-    auto kern = attn_kernel<D16, DT>;
+    auto kern = attn_kernel<D16, DT, ONES, QT>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -223,12 +275,25 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 extern "C" {
 
+// V^T contract: when d is not a multiple of 32, row d of every [dp][tok_pad] matrix must hold ones (softmax
+// denominator through the PV MFMA).  Call once after allocating / zeroing the buffer; the QKV epilogue never
+// writes rows >= d.
+int cfgpp_op_attention_prepare_vt(void* vt, int BH, int d, int tok_pad, void* stream) {
+    CFGPP_REQUIRE(vt && BH > 0 && d > 0 && tok_pad > 0, "attention_prepare_vt: bad args");
+    if (d % 32 == 0) return 0;
+    CFGPP_REQUIRE(d % 8 == 0, "attention: head dim %d (not a multiple of 32) must be a multiple of 8", d);
+    const int dp = (d + 31) / 32 * 32;
+    hipLaunchKernelGGL(attn_ones_row_kernel, dim3(cdiv((long)BH * tok_pad, 256)), dim3(256), 0, (hipStream_t)stream, (half_t*)vt, BH, d, dp, tok_pad);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // q [B*heads][q_tok_pad][dp], k [B*heads][k_tok_pad][dp], vt [B*heads][dp][k_tok_pad], all fp16, dp = round_up(d,32),
-// pads zero.  o [B][nq][heads*d] fp16.  q_tok_pad % 128 == 0, k_tok_pad % 64 == 0.
+// pads zero EXCEPT the ones row of vt (above).  o [B][nq][heads*d] fp16.  q_tok_pad % 128 == 0, k_tok_pad % 64 == 0.
 int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream) {
     CFGPP_REQUIRE(q && k && vt && o, "attention: null pointer");
-    CFGPP_REQUIRE(d % 4 == 0 && d > 0 && d <= 160, "attention: head dim %d unsupported (multiple of 4, <= 160)", d);
+    CFGPP_REQUIRE(d > 0 && d <= 160 && (d % 32 == 0 || d % 8 == 0), "attention: head dim %d unsupported (multiple of 8, <= 160)", d);
     CFGPP_REQUIRE(q_tok_pad % 128 == 0 && q_tok_pad >= nq, "attention: q_tok_pad=%d (nq=%d) must be a multiple of 128", q_tok_pad, nq);
     CFGPP_REQUIRE(k_tok_pad % 64 == 0 && k_tok_pad >= nk, "attention: k_tok_pad=%d (nk=%d) must be a multiple of 64", k_tok_pad, nk);
     AttnArgs a;
@@ -239,8 +304,9 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     dim3 grid(cdiv(nq, 128), B * heads);
     hipStream_t s = (hipStream_t)stream;
     const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
+    const bool ones = (d % 32) != 0;
 #define ATTN_CASE(D16_, DT_) \
-    if (d16 == D16_ && dt == DT_) { if (launch_attn<D16_, DT_>(a, grid, s)) return -1; } else
+    if (d16 == D16_ && dt == DT_) { if (ones ? launch_attn<D16_, DT_, true, 1>(a, grid, s) : launch_attn<D16_, DT_, false, 1>(a, grid, s)) return -1; } else
     ATTN_CASE(1, 1) ATTN_CASE(2, 1) ATTN_CASE(3, 2) ATTN_CASE(4, 2) ATTN_CASE(5, 3) ATTN_CASE(6, 3)
     ATTN_CASE(8, 4) ATTN_CASE(10, 5)
     { cfgpp_set_error("attention: no kernel instance for head dim %d", d); return -2; }

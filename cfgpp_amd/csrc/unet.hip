@@ -195,6 +195,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
                 u->hk[i] = (half_t*)u->dmalloc((size_t)R * c.num_heads[i] * round_up((int)tok, 128) * dp * 2);
                 u->hvt[i] = (half_t*)u->dmalloc((size_t)R * c.num_heads[i] * dp * round_up((int)tok, 64) * 2);
                 CFGPP_REQUIRE(u->hq[i] && u->hk[i] && u->hvt[i], "finalize: hipMalloc failed");
+                if (cfgpp_op_attention_prepare_vt(u->hvt[i], R * c.num_heads[i], d, round_up((int)tok, 64), nullptr)) return -1;
             }
             if (i != L - 1) { H /= 2; W /= 2; }
         }
@@ -342,6 +343,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             // persistent cross-attention K / V^T of this block (filled by set_context)
             half_t* ck = (half_t*)u->dmalloc((size_t)R * nheads * ck_pad * dp * 2);
             half_t* cvt = (half_t*)u->dmalloc((size_t)R * nheads * dp * ck_pad * 2);
+            if (!ck || !cvt || cfgpp_op_attention_prepare_vt(cvt, R * nheads, d, ck_pad, nullptr)) { B.ok = false; B.err = "cross-attention K/V^T allocation failed"; }
             {
                 cfgpp_unet* uu = u; const int Dc = c.cross_attention_dim; const int ckp = ck_pad;
                 IGemmArgs a = base_args();

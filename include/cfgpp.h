@@ -152,6 +152,9 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
                        int dst_padded, void* stream);
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream);
+/* V^T contract of cfgpp_op_attention: when d % 32 != 0, row d of every [dp][tok_pad] matrix holds ones
+ * (softmax denominator through the PV MFMA).  Call once on the zero-initialised buffer. */
+int cfgpp_op_attention_prepare_vt(void* vt, int BH, int d, int tok_pad, void* stream);
 int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,

@@ -282,7 +282,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     out["q"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
     out["k"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
     out["vt"] = H.err_stats(hvt[:, :d, :tokens].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
-    out["pad_zero"] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :, tokens:].abs().sum() == 0)
+    out["pad_zero"] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :d, tokens:].abs().sum() == 0 and hvt[:, d + 1:].abs().sum() == 0)
     return out
 
 

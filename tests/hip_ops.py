@@ -138,6 +138,7 @@ def heads_project(a, w, B, tokens, C, nheads, part0, nparts, q_pad, k_pad):
     hq = torch.zeros((B * nheads, q_pad, dp), dtype=torch.float16, device=DEV)
     hk = torch.zeros((B * nheads, k_pad, dp), dtype=torch.float16, device=DEV)
     hvt = torch.zeros((B * nheads, dp, k_pad), dtype=torch.float16, device=DEV)
+    check(lib().cfgpp_op_attention_prepare_vt(P(hvt), B * nheads, d, k_pad, stream()), "cfgpp_op_attention_prepare_vt")
     check(lib().cfgpp_op_igemm_heads(P(a), a.shape[1], P(w), a.shape[0], w.shape[0], None, tokens, P(hq), P(hk),
                                      P(hvt), part0, C, d, nheads, q_pad, k_pad, stream()), "cfgpp_op_igemm_heads")
     return hq, hk, hvt
@@ -155,6 +156,7 @@ def make_heads(q, k, v):
     hq[:, :Nq, :d] = q.reshape(B * h, Nq, d).to(DEV, torch.float16)
     hk[:, :Nk, :d] = k.reshape(B * h, Nk, d).to(DEV, torch.float16)
     hvt[:, :d, :Nk] = v.reshape(B * h, Nk, d).transpose(1, 2).to(DEV, torch.float16)
+    check(lib().cfgpp_op_attention_prepare_vt(P(hvt), B * h, d, k_pad, stream()), "cfgpp_op_attention_prepare_vt")   # ones row when d % 32 != 0
     return hq, hk, hvt, q_pad, k_pad
 
 
