@@ -82,7 +82,6 @@ PROTOTYPES = {
     "cfgpp_igemm_set_staging": (None, [_I]),
     "cfgpp_igemm_set_staged_epilogue": (None, [_I]),
     "cfgpp_igemm_set_big_tiles": (None, [_I]),
-    "cfgpp_igemm_set_debug": (None, [_I]),
     "cfgpp_igemm_set_tail_split": (None, [_I]),
     "cfgpp_igemm_set_autotune": (None, [_I]),
 }

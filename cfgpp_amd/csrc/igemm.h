@@ -47,7 +47,6 @@ struct IGemmArgs {
     int cfg_hint;             // 0 = heuristic; 1/4/5/6 = tile config pinned by the engine's in-situ tuning pass
     int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
     int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
-    int dbg;                  // ablation (benchmarks only): bit0 = no tile loads after the first, bit1 = no MFMA
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);

@@ -693,8 +693,6 @@ static int g_staged_epi = 1;
 extern "C" void cfgpp_igemm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 : 0; }
 static int g_big_tiles = 1;
 extern "C" void cfgpp_igemm_set_big_tiles(int on) { g_big_tiles = on ? 1 : 0; }
-static int g_dbg = 0;
-extern "C" void cfgpp_igemm_set_debug(int flags) { g_dbg = flags; }   // ablation hooks are compiled out of the product kernel
 static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
 
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
@@ -713,7 +711,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
-    a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.dbg = g_dbg; a.staged_epi = g_staged_epi;
+    a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.staged_epi = g_staged_epi;
     // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
     // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
     // finishes them.  S is chosen so that T*S fills the resident slots once or twice.

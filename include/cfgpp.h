@@ -187,7 +187,6 @@ void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K i
 /* 1 (default): the first launch of every GEMM shape times the candidate tile configs and keeps the fastest
  * (results are bit-identical across candidates; K-split launches are rule-based). 0: fixed heuristic. */
 void cfgpp_igemm_set_autotune(int on);
-void cfgpp_igemm_set_debug(int flags);    /* benchmark ablation: bit0 skip tile loads, bit1 skip MFMA */
 void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x320 tiles (default) */
 void cfgpp_igemm_set_staged_epilogue(int on); /* 1 = LDS-transposed row-coalesced store epilogue (default) */
 void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */

@@ -12,7 +12,6 @@ SHAPES = [  # name, kind, batch rows, HW side, Cin, Cout(N)
     ("xl_geglu_32", "lin", 4, 32, 1280, 10240), ("xl_ffout_32", "lin", 4, 32, 5120, 1280), ("xl_qkv_32", "lin", 4, 32, 1280, 3840),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-H.lib().cfgpp_igemm_set_debug(int(os.environ.get("DBG", "0")))
 cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,2,3,11,12,13").split(",")]
 iters = int(os.environ.get("ITERS", "20"))
 def timeit(fn):
