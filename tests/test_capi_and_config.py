@@ -56,3 +56,20 @@ def test_oracle_unet_runs_and_is_finite():
     out = net(torch.randn(2, 4, 16, 16), 500.0, torch.randn(2, 77, cfg.cross_attention_dim) * 0.5,
               {"text_embeds": torch.randn(1, cfg.addition_pooled_dim), "time_ids": torch.tensor([[128.0, 128, 0, 0, 128, 128]])})["sample"]
     assert out.shape == (2, 4, 16, 16) and torch.isfinite(out).all()
+
+
+def test_safetensors_loader_streams_diffusers_keys(tmp_path):
+    """weights.load_safetensors_iter (the real-checkpoint path of HipEngine / vae_weights=) yields every key
+    of a diffusers-layout file unchanged."""
+    import torch
+    from safetensors.torch import save_file
+    from cfgpp_amd.unet_config import TINY_SD, param_shapes
+    from cfgpp_amd.weights import load_safetensors_iter, synth_tensor
+    shapes = dict(list(param_shapes(TINY_SD).items())[:12])
+    sd = {k: synth_tensor(k, s, 0).half() for k, s in shapes.items()}
+    path = str(tmp_path / "unet.safetensors")
+    save_file(sd, path)
+    got = dict(load_safetensors_iter(path))
+    assert set(got) == set(sd)
+    for k in sd:
+        assert got[k].dtype == torch.float16 and torch.equal(got[k], sd[k])

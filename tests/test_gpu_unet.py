@@ -101,3 +101,64 @@ def test_unet_forward_is_bitwise_deterministic():
     a = net.forward(z, 500.0).clone()
     for _ in range(3):
         assert torch.equal(net.forward(z, 500.0), a)
+
+
+def test_unet_output_does_not_depend_on_tile_tuning():
+    """The in-situ tile tuning may pin any non-split tile config per launch; every one of them runs the K loop
+    in the same order, so the forward must be BIT-identical with tuning on, off, and with a forced config.
+    (K-split launches sum in a different order; they are rule-based, never tuned, and switched off here because a
+    FORCED config would otherwise un-split launches that the rule splits.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from cfgpp_amd import _lib
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import TINY_SD as cfg
+    from cfgpp_amd.weights import synth_state_dict
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn(8, 77, cfg.cross_attention_dim, generator=g) * 0.5
+    z = torch.randn(4, 4, 32, 32, generator=g).cuda()
+    outs = []
+    try:
+        lib.cfgpp_igemm_set_tail_split(0)
+        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6)):
+            lib.cfgpp_igemm_set_autotune(tune)
+            lib.cfgpp_igemm_force_config(force)
+            net = HipUNet(cfg, 8, (32, 32))
+            net.load_state_dict(synth_state_dict(cfg)).finalize()
+            net.set_context(ctx)
+            outs.append(net.forward(z, 321.0).clone())
+            del net
+    finally:
+        lib.cfgpp_igemm_set_autotune(1)
+        lib.cfgpp_igemm_force_config(0)
+        lib.cfgpp_igemm_set_tail_split(1)
+    assert torch.isfinite(outs[0].float()).all()
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(o, outs[0]), f"variant {i + 1} differs: max |d| = {float((o.float() - outs[0].float()).abs().max()):.3e}"
+
+
+def test_unet_output_same_with_tuning_on_and_off_including_split_launches():
+    """default settings (K-split on): tuning on vs off must still be bit-identical - split launches are never tuned"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from cfgpp_amd import _lib
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import TINY_SD as cfg
+    from cfgpp_amd.weights import synth_state_dict
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    ctx = torch.randn(8, 77, cfg.cross_attention_dim, generator=g) * 0.5
+    z = torch.randn(4, 4, 32, 32, generator=g).cuda()
+    outs = []
+    try:
+        for tune in (0, 1):
+            lib.cfgpp_igemm_set_autotune(tune)
+            net = HipUNet(cfg, 8, (32, 32))
+            net.load_state_dict(synth_state_dict(cfg)).finalize()
+            net.set_context(ctx)
+            outs.append(net.forward(z, 321.0).clone())
+            del net
+    finally:
+        lib.cfgpp_igemm_set_autotune(1)
+    assert torch.equal(outs[0], outs[1])
