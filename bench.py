@@ -93,7 +93,7 @@ def cpu_baseline_child(cfg_name, name, nfe, lam, img):
     decode), printed as JSON lines as soon as each part is measured."""
     from cfgpp_amd.schedule import SchedulerTables
     from cfgpp_amd.unet_config import CONFIGS
-    from cfgpp_amd.vae import TorchVAE
+    from oracle.vae_ref import VAERef as TorchVAE
     from cfgpp_amd.weights import synth_state_dict
     from oracle import sampler as O
     from oracle.unet_ref import UNetRef

@@ -19,6 +19,7 @@ from typing import Any, Callable, Dict, List, Optional
 import torch
 
 from . import coeffs as K
+from ._lib import CfgppError
 from .conditioning import SyntheticTextEncoder, as_list
 from .schedule import SchedulerTables, get_ancestral_step, get_sigmas_karras  # noqa: F401
 from .unet_config import SD15, UNetConfig
@@ -126,13 +127,11 @@ class StableDiffusion:
 
     def _get_vae(self):
         if self.vae is None:
-            if self.work_device.type == "cuda":
-                from .vae import HipVAE          # decoder on the HIP kernels; no fallback
-                self.vae = HipVAE(self.cfg.vae_scale, self.latent_hw, max_batch=self.max_batch, device=self.work_device,
-                                  **self._vae_kwargs)
-            else:                                # only reachable with an injected (test) engine on CPU
-                from .vae import TorchVAE
-                self.vae = TorchVAE(self.cfg.vae_scale, device=self.work_device, dtype=torch.float32, **self._vae_kwargs)
+            if self.work_device.type != "cuda":      # CPU is only reachable with an injected (test) engine: inject the VAE too
+                raise CfgppError("decode/encode need the HIP VAE (ROCm GPU); on CPU pass vae=<object with decode/encode>")
+            from .vae import HipVAE                  # decoder + encoder on the HIP kernels; no fallback
+            self.vae = HipVAE(self.cfg.vae_scale, self.latent_hw, max_batch=self.max_batch, device=self.work_device,
+                              **self._vae_kwargs)
         return self.vae
 
     def encode(self, x):

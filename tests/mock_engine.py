@@ -133,3 +133,19 @@ class MockEngine:
 
     def randn_like(self, x):
         return torch.randn_like(x)
+
+
+class StubVAE:
+    """Shape-correct stand-in for the VAE in CPU solver tests (trajectories are compared on latents):
+    decode = nearest x8 of the first 3 latent channels / scale, encode = 8x8 mean pool * scale (+ a zero channel)."""
+
+    def __init__(self, scale: float):
+        self.scale = float(scale)
+
+    def decode(self, zt):
+        z = zt.float() / self.scale
+        return torch.nn.functional.interpolate(z[:, :3], scale_factor=8.0, mode="nearest")
+
+    def encode(self, x, **_):
+        m = torch.nn.functional.avg_pool2d(x.float(), 8)
+        return torch.cat([m, torch.zeros_like(m[:, :1])], 1) * self.scale

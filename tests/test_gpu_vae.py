@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 def test_vae_decode_vs_cpu_reference(hw, B):
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
-    from cfgpp_amd.vae import HipVAE, TorchVAE, synth_vae_state_dict
+    from cfgpp_amd.vae import HipVAE, synth_vae_state_dict
+    from oracle.vae_ref import VAERef as TorchVAE
     sd = synth_vae_state_dict(0)
     g = torch.Generator().manual_seed(1)
     z = torch.randn((B, 4) + hw, generator=g) * 0.18215 * 1.5
@@ -29,7 +30,8 @@ def test_vae_encode_vs_cpu_reference(hw, B):
     posterior kernel) vs the fp32 torch restatement; the posterior noise is pinned so the sample is comparable."""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
-    from cfgpp_amd.vae import HipVAE, TorchVAE, synth_vae_state_dict
+    from cfgpp_amd.vae import HipVAE, synth_vae_state_dict
+    from oracle.vae_ref import VAERef as TorchVAE
     sd = synth_vae_state_dict(0)
     g = torch.Generator().manual_seed(2)
     img = (torch.rand((B, 3, 8 * hw[0], 8 * hw[1]), generator=g) * 2 - 1)

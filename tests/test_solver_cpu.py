@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from _stub_env import fake_embed, pointwise_eps
-from mock_engine import MockEngine
+from mock_engine import MockEngine, StubVAE
 
 import cfgpp_amd.latent_diffusion as sd
 import cfgpp_amd.latent_sdxl as xl
@@ -54,14 +54,15 @@ class Rec:
 
 def make_sd(name, nfe):
     eng = MockEngine(scripted_unet)
-    s = sd.get_solver(name, solver_config=cfgn(nfe), device="cpu", engine=eng, text_encoder=StubSDText(), latent_hw=(8, 8))
+    s = sd.get_solver(name, solver_config=cfgn(nfe), device="cpu", engine=eng, text_encoder=StubSDText(), latent_hw=(8, 8),
+                      vae=StubVAE(0.18215))
     return s, eng
 
 
 def make_xl(name, nfe):
     eng = MockEngine(scripted_unet)
     s = xl.get_solver(name, solver_config=cfgn(nfe), device="cpu", engine=eng,
-                      text_encoder=(StubXLText("L", 768), StubXLText("G", 1280)), latent_hw=(8, 8))
+                      text_encoder=(StubXLText("L", 768), StubXLText("G", 1280)), latent_hw=(8, 8), vae=StubVAE(0.13025))
     return s, eng
 
 
