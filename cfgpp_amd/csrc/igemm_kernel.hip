@@ -57,7 +57,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    // opaque per (i, j, g): keeps the compiler from hoisting ~50 column pointers out of the i loop
+                    // (they were spilled to scratch on the 10-accumulator-tile config)
+                    asm volatile("" : "+v"(n));
                     if (n >= p.N) continue;
                     float v[4];
 #pragma unroll
@@ -82,7 +85,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                 }
         } else if (p.epi == EPI_GEGLU) {
             // packed columns: within every 64 packed columns, [0,32) = value, [32,64) = gate
-            if constexpr (NT >= 2) {
+            if constexpr (NT % 2 == 0) {
 #pragma unroll
                 for (int j = 0; j < NT; j += 2)
 #pragma unroll
@@ -110,7 +113,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    int n = nw0 + j * 32 + 8 * g + 4 * fhi;
+                    asm volatile("" : "+v"(n));
                     if (n >= p.N) continue;
                     const int part = n / p.part_width + p.part0;
                     const int cn = n % p.part_width;
