@@ -49,6 +49,11 @@ gn_stats_kernel(GNArgs a) {
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
     const int ppi = max(1, (int)blockDim.x / chunks);        // pixels per iteration
+    // padded offset of pixel p of sample n without an integer division: pad_off = base + p + 2*(p / W), and
+    // p / W = floor((p + 0.5) / W) is exact in fp32 here (p < 2^20, H <= 1024: error 1e-4 << margin 0.5 / W)
+    const float invW = 1.0f / (float)a.W;
+    const long pbase = (long)n * (a.H + 2) * (a.W + 2) + (a.W + 2) + 1;
+    auto poff = [&](int p) -> long { return pbase + p + 2 * (int)(((float)p + 0.5f) * invW); };
     float gsum = 0.f, gsq = 0.f;                             // thread g < G owns group g
     for (int cbase = 0; cbase < chunks; cbase += blockDim.x) {
         int chunk, psub;
@@ -62,9 +67,19 @@ gn_stats_kernel(GNArgs a) {
             const int c = chunk * 8;
             const half_t* src; int cs, Cs;
             if (c < a.C0) { src = a.src0; cs = c; Cs = a.C0; } else { src = a.src1; cs = c - a.C0; Cs = a.C1; }
-            for (int p = p0 + psub; p < p1; p += ppi) {
-                const int y = p / a.W, x = p - y * a.W;
-                const half8_t v = *reinterpret_cast<const half8_t*>(src + pad_off(n, y, x, a.H, a.W) * Cs + cs);
+            // 4 independent 16-B loads in flight per thread; the per-thread summation order is unchanged
+            int p = p0 + psub;
+            for (; p + 3 * ppi < p1; p += 4 * ppi) {
+                half8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8_t*>(src + poff(p + u * ppi) * Cs + cs);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { float f = (float)v[u][k]; s[k] += f; q[k] += f * f; }
+            }
+            for (; p < p1; p += ppi) {
+                const half8_t v = *reinterpret_cast<const half8_t*>(src + poff(p) * Cs + cs);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { float f = (float)v[k]; s[k] += f; q[k] += f * f; }
             }
@@ -130,6 +145,11 @@ gn_apply_kernel(GNArgs a) {
     }
     __syncthreads();
     const int ppi = max(1, (int)blockDim.x / chunks);
+    // padded offset of pixel p of sample n without an integer division: pad_off = base + p + 2*(p / W), and
+    // p / W = floor((p + 0.5) / W) is exact in fp32 here (p < 2^20, H <= 1024: error 1e-4 << margin 0.5 / W)
+    const float invW = 1.0f / (float)a.W;
+    const long pbase = (long)n * (a.H + 2) * (a.W + 2) + (a.W + 2) + 1;
+    auto poff = [&](int p) -> long { return pbase + p + 2 * (int)(((float)p + 0.5f) * invW); };
     for (int cbase = 0; cbase < chunks; cbase += blockDim.x) {
         int chunk, psub;
         if (chunks <= (int)blockDim.x) { chunk = threadIdx.x % chunks; psub = threadIdx.x / chunks; }
@@ -146,10 +166,7 @@ gn_apply_kernel(GNArgs a) {
                 const float ga = a.gamma[c + k] * s_rstd[g];
                 sc[k] = ga; sh[k] = a.beta[c + k] - s_mean[g] * ga;
             }
-            for (int p = p0 + psub; p < p1; p += ppi) {
-                const int y = p / a.W, x = p - y * a.W;
-                const long po = pad_off(n, y, x, a.H, a.W);
-                const half8_t v = *reinterpret_cast<const half8_t*>(src + po * Cs + cs);
+            auto one = [&](int p, const half8_t v, long po) {
                 half8_t o;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -159,6 +176,18 @@ gn_apply_kernel(GNArgs a) {
                 }
                 const long orow = a.dst_padded ? po : ((long)n * HW + p);
                 *reinterpret_cast<half8_t*>(a.dst + orow * C + c) = o;
+            };
+            int p = p0 + psub;
+            for (; p + 3 * ppi < p1; p += 4 * ppi) {       // 4 independent 16-B loads in flight per thread
+                half8_t v[4]; long po[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { po[u] = poff(p + u * ppi); v[u] = *reinterpret_cast<const half8_t*>(src + po[u] * Cs + cs); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) one(p + u * ppi, v[u], po[u]);
+            }
+            for (; p < p1; p += ppi) {
+                const long po = poff(p);
+                one(p, *reinterpret_cast<const half8_t*>(src + po * Cs + cs), po);
             }
         }
         if (chunks <= (int)blockDim.x) break;
