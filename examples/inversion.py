@@ -1,0 +1,75 @@
+"""Command-line twin of the reference's examples/inversion.py (same flags and defaults) on the MI355X path:
+encode an image, DDIM-invert it under the source prompt and reconstruct it (``ddim_inversion`` /
+``ddim_inversion_cfg++`` / ``ddim_edit*``).
+
+    python examples/inversion.py --img_path cat.jpg --prompt "a photo of a cat" --method ddim_inversion_cfg++ \
+        --cfg_guidance 0.6 --NFE 10 [--model sd15|sdxl] [--unet_weights ... --vae_weights ...]
+
+Additive flags as in text_to_img.py.  The VAE posterior noise is drawn from the CPU generator seeded by
+``--seed`` (the reference samples it on the device, which is not reproducible across devices).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def load_img(img_path, size: int = 512) -> torch.Tensor:
+    """RGB image file -> [1,3,size,size] float in [-1, 1] (what ``solver.encode`` expects)."""
+    from PIL import Image
+    arr = np.asarray(Image.open(img_path).convert("RGB").resize((size, size)), dtype=np.float32)
+    return (torch.from_numpy(arr).permute(2, 0, 1) / 127.5 - 1.0).unsqueeze(0)
+
+
+def main(argv=None, solver_kwargs=None) -> None:
+    """``solver_kwargs`` lets tests inject ``engine=`` / ``vae=`` (CPU mock); the CLI never passes it."""
+    ap = argparse.ArgumentParser(description="Latent Diffusion inversion (CFG++) on MI355X")
+    ap.add_argument("--workdir", type=Path, default=Path("examples/workdir/inversion"))
+    ap.add_argument("--img_path", type=Path, default=Path("examples/assets/afhq_1.jpg"))
+    ap.add_argument("--img_size", type=int, default=512)
+    ap.add_argument("--device", type=str, default="cuda")
+    ap.add_argument("--null_prompt", type=str, default="")
+    ap.add_argument("--prompt", type=str, default="")
+    ap.add_argument("--cfg_guidance", type=float, default=7.5)
+    ap.add_argument("--method", type=str, default="ddim_inversion_cfg++")
+    ap.add_argument("--model", type=str, default="sd15", choices=["sd15", "sd20", "sdxl"])
+    ap.add_argument("--NFE", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--unet_weights", type=str, default="synthetic")
+    ap.add_argument("--vae_weights", type=str, default=None)
+    args = ap.parse_args(argv)
+
+    from cfgpp_amd.callback_util import save_image
+    (args.workdir / "result").mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(args.seed)
+    xl = args.model == "sdxl"
+    size = args.img_size if not xl or args.img_size != 512 else 1024
+    img = load_img(args.img_path, size)
+    kw = dict(solver_config=types.SimpleNamespace(num_sampling=args.NFE), device=args.device, max_batch=1,
+              unet_weights=args.unet_weights, latent_hw=(size // 8, size // 8))
+    if args.vae_weights:
+        kw["vae_weights"] = args.vae_weights
+    kw.update(solver_kwargs or {})
+    if xl:
+        from cfgpp_amd.latent_sdxl import get_solver
+        solver = get_solver(args.method, **kw)
+        result = solver.sample(prompt1=[args.null_prompt, args.prompt, args.prompt], prompt2=[args.null_prompt, args.prompt, args.prompt],
+                               src_img=img, cfg_guidance=args.cfg_guidance, target_size=(size, size), callback_fn=None)
+    else:
+        from cfgpp_amd.latent_diffusion import get_solver
+        solver = get_solver(args.method, **kw)
+        result = solver.sample(prompt=[args.null_prompt, args.prompt], src_img=img, cfg_guidance=args.cfg_guidance, callback_fn=None)
+    save_image(result, args.workdir / "result" / "reconstruct.png")
+    print(f"saved {args.workdir / 'result' / 'reconstruct.png'}")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main() -> None:
+def main(argv=None, solver_kwargs=None) -> None:
+    """``solver_kwargs`` lets tests inject ``engine=`` / ``vae=`` (CPU mock); the CLI never passes it."""
     ap = argparse.ArgumentParser(description="Latent Diffusion (CFG++) on MI355X")
     ap.add_argument("--workdir", type=Path, default=Path("examples/workdir/t2i"))
     ap.add_argument("--device", type=str, default="cuda")
@@ -39,7 +40,7 @@ def main() -> None:
     ap.add_argument("--vae_weights", type=str, default=None)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--draw", action="store_true", help="save z0t / zt decodes every step (draw_tweedie + draw_noisy)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     from cfgpp_amd.callback_util import ComposeCallback, save_image
     (args.workdir / "result").mkdir(parents=True, exist_ok=True)
@@ -49,6 +50,7 @@ def main() -> None:
     kw = dict(solver_config=cfg, device=args.device, max_batch=args.batch, unet_weights=args.unet_weights)
     if args.vae_weights:
         kw["vae_weights"] = args.vae_weights
+    kw.update(solver_kwargs or {})
     prompts = [args.prompt] * args.batch if args.batch > 1 else args.prompt
     seeds = None if args.batch == 1 else [args.seed + i for i in range(args.batch)]   # B = 1: global CPU RNG, like the reference
 
