@@ -40,3 +40,71 @@ class SyntheticTextEncoder:
 
 def as_list(p) -> List[str]:
     return [p] if isinstance(p, str) else list(p)
+
+
+class HashTokenizer:
+    """Vocabulary-free stand-in for the CLIP BPE tokenizer (no vocab.json / merges.txt exist offline): lower-cased
+    word pieces hashed into the 49 406 ordinary ids, BOS 49406 / EOS 49407, padded to 77 with ``pad_id``
+    (EOS for CLIP-L, 0 for OpenCLIP-bigG, as the SDXL tokenizers do).  Same token layout as the real one -
+    [BOS, words..., EOS, pad...] - so the towers below see realistic sequences and the EOS pooling works."""
+
+    BOS, EOS, VOCAB = 49406, 49407, 49408
+
+    def __init__(self, pad_id: Optional[int] = None, length: int = 77):
+        self.pad_id = self.EOS if pad_id is None else pad_id
+        self.length = length
+
+    def __call__(self, prompts: List[str]) -> torch.Tensor:
+        import re
+        out = torch.full((len(prompts), self.length), self.pad_id, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            words = re.findall(r"[a-z0-9]+|[^\sa-z0-9]", p.lower())[: self.length - 2]
+            ids = [self.BOS] + [_seed(w, "tok") % 49406 for w in words] + [self.EOS]
+            out[i, : len(ids)] = torch.tensor(ids)
+        return out
+
+
+class ClipTextTower:
+    """A CLIP text transformer on torch ops (``transformers`` architecture): the reference's
+    ``text_encoder(tokens)[0]`` (SD1.5, latent_diffusion.py:105-113) or ``hidden_states[-2]`` + projected pooled
+    output (SDXL, latent_sdxl.py:76-93).  Runs once per prompt, off the per-step path, so it stays on
+    torch-ROCm ops.  Weights: a ``transformers`` state dict / safetensors path, or seeded random init (no
+    checkpoint exists offline).  Opt-in: ``get_solver(..., text_encoder=ClipTextTower.clip_l())``.
+
+    ``encode(list[str]) -> (hidden [n,77,D] fp16, pooled [n,P] fp16 | None)`` like every text encoder here."""
+
+    def __init__(self, hidden: int, layers: int, heads: int, intermediate: int, act: str, proj_dim: Optional[int],
+                 penultimate: bool, pad_id: Optional[int], device="cpu", dtype=torch.float32, weights=None, seed: int = 0):
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+        cfg = CLIPTextConfig(vocab_size=HashTokenizer.VOCAB, hidden_size=hidden, intermediate_size=intermediate,
+                             num_hidden_layers=layers, num_attention_heads=heads, max_position_embeddings=77,
+                             hidden_act=act, projection_dim=proj_dim or hidden, bos_token_id=HashTokenizer.BOS,
+                             eos_token_id=HashTokenizer.EOS, pad_token_id=1)
+        torch.manual_seed(seed)
+        self.model = (CLIPTextModelWithProjection(cfg) if proj_dim else CLIPTextModel(cfg)).eval()
+        if weights is not None:
+            if isinstance(weights, str):
+                from .weights import load_safetensors_iter
+                weights = dict(load_safetensors_iter(weights))
+            self.model.load_state_dict(weights)
+        self.model.to(device=device, dtype=dtype)
+        self.tok = HashTokenizer(pad_id)
+        self.penultimate, self.proj = penultimate, bool(proj_dim)
+        self.device = device
+
+    @classmethod
+    def clip_l(cls, **kw):        # SD1.5 text encoder / SDXL text_encoder (12 layers, 768 wide)
+        kw.setdefault("penultimate", False)
+        return cls(768, kw.pop("layers", 12), 12, 3072, "quick_gelu", None, kw.pop("penultimate"), None, **kw)
+
+    @classmethod
+    def open_clip_bigg(cls, **kw):  # SDXL text_encoder_2 (32 layers, 1280 wide, projected pooled output)
+        return cls(1280, kw.pop("layers", 32), 20, 5120, "gelu", 1280, True, 0, **kw)
+
+    @torch.no_grad()
+    def __call__(self, prompts: List[str]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        ids = self.tok(prompts).to(self.device)
+        out = self.model(input_ids=ids, output_hidden_states=True)
+        hs = out.hidden_states[-2] if self.penultimate else out.last_hidden_state
+        pooled = out.text_embeds if self.proj else None
+        return hs.to(torch.float16), (None if pooled is None else pooled.to(torch.float16))

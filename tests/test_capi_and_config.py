@@ -73,3 +73,20 @@ def test_safetensors_loader_streams_diffusers_keys(tmp_path):
     assert set(got) == set(sd)
     for k in sd:
         assert got[k].dtype == torch.float16 and torch.equal(got[k], sd[k])
+
+
+def test_clip_text_towers_shapes_and_determinism():
+    """opt-in CLIP text towers (transformers architecture, random init, hash tokenizer): SD1.5 / SDXL contracts"""
+    import torch
+    from cfgpp_amd.conditioning import ClipTextTower, HashTokenizer
+    ids = HashTokenizer()(["a photo of a cat", ""])
+    assert ids.shape == (2, 77) and ids[0, 0] == 49406 and ids[1, 1] == 49407 and ids[0, 6] == 49407
+    assert (HashTokenizer(pad_id=0)(["x"])[0, 3:] == 0).all()
+    enc = ClipTextTower.clip_l(layers=1)
+    hs, pooled = enc(["a photo of a cat", "a dog"])
+    assert hs.shape == (2, 77, 768) and hs.dtype == torch.float16 and pooled is None and torch.isfinite(hs.float()).all()
+    assert torch.equal(hs, ClipTextTower.clip_l(layers=1)(["a photo of a cat", "a dog"])[0])       # seeded init
+    l_pen = ClipTextTower.clip_l(layers=2, penultimate=True)
+    g = ClipTextTower.open_clip_bigg(layers=2)
+    h1, _ = l_pen(["a cat"]); h2, p2 = g(["a cat"])
+    assert torch.cat([h1, h2], -1).shape == (1, 77, 2048) and p2.shape == (1, 1280)

@@ -40,3 +40,16 @@ def test_inversion_cli_reconstructs(tmp_path):
     im = Image.open(tmp_path / "result" / "reconstruct.png")
     assert im.size == (64, 64)
     assert torch.isfinite(torch.from_numpy(np.asarray(im, dtype=np.float32))).all()
+
+
+def test_solver_with_clip_text_tower():
+    """the opt-in CLIP tower plugs into the SD1.5 solver through the same ``text_encoder=`` seam as the synthetic one"""
+    import types
+    from cfgpp_amd.conditioning import ClipTextTower
+    from cfgpp_amd.latent_diffusion import get_solver
+    eng = MockEngine(_unet, (8, 8))
+    s = get_solver("ddim_cfg++", solver_config=types.SimpleNamespace(num_sampling=2), device="cpu", engine=eng,
+                   text_encoder=ClipTextTower.clip_l(layers=1), latent_hw=(8, 8), vae=StubVAE(0.18215))
+    img = s.sample(prompt=["", "a cat"], cfg_guidance=0.6)
+    assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
+    assert eng.ehs.shape == (2, 77, 768) and eng.ehs.dtype == torch.float16
