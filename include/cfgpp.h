@@ -13,7 +13,8 @@
  * Conventions: plain C types only; every data pointer is a DEVICE pointer owned
  * by the caller (PyTorch-ROCm tensor storage) unless the name says `host`; all
  * work is enqueued asynchronously on the hipStream_t passed as `void* stream`
- * and nothing synchronises; return 0 on success, < 0 on error with a message in
+ * and nothing synchronises (one exception: the tile-tuning passes of the first
+ * forward at a batch size, see cfgpp_igemm_set_autotune); return 0 on success, < 0 on error with a message in
  * cfgpp_last_error() (thread-local).  One context per device; not thread-safe.
  */
 #ifndef CFGPP_H
@@ -123,7 +124,7 @@ double cfgpp_unet_flops(cfgpp_unet* u, int rows);
 /* Bytes of device memory held (weights + activations). */
 double cfgpp_unet_device_bytes(cfgpp_unet* u);
 
-/* ---- VAE decoder engine (replaces `self.vae.decode(z / scale).sample`) ------
+/* ---- VAE engine: decoder (replaces `self.vae.decode(z / scale).sample`) and encoder ------
  * latent_diffusion.py:123-129 (scale 0.18215), latent_sdxl.py:155-164 (vae.config.scaling_factor).
  * Weights by diffusers AutoencoderKL keys (post_quant_conv.*, decoder.*).  img fp32 [B][3][8h][8w]. */
 typedef struct cfgpp_vae cfgpp_vae;
@@ -172,7 +173,8 @@ int cfgpp_op_f16_to_f32_rows(const void* in, float* out, int rows, int cols, int
 
 /* Generic implicit GEMM (conv3x3 / conv1x1 / linear), see cfgpp_amd/csrc/igemm.h.
  * a0/a1: activation sources (C0/C1 channels), amode 0 linear rows, 1 halo-padded NHWC,
- * 2 padded stride-2, 3 padded nearest-2x upsample; w [N][taps*(C0+C1)] fp16 (k = tap*Cin + c);
+ * 2 padded stride-2, 3 padded nearest-2x upsample; w [N][taps*(C0+C1)] fp16 with K order channel-block major,
+ * tap minor: k = (cb*taps + tap)*64 + c, cb = 64-channel block of the concatenated input;
  * epi 0 store (+bias +temb +resid), 1 GEGLU (packed weights).  omode/rmode: 0 linear, 1 padded. */
 int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int amode, int H, int W,
                    const void* w, int M, int N, const float* bias, const float* temb, int temb_ld,
@@ -184,8 +186,9 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128; 11..13 = register-staged 1..3 */
 void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
-/* 1 (default): the first launch of every GEMM shape times the candidate tile configs and keeps the fastest
- * (results are bit-identical across candidates; K-split launches are rule-based). 0: fixed heuristic. */
+/* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
+ * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins
+ * the fastest; results are bit-identical across candidates, K-split launches stay rule-based.  0: fixed heuristic. */
 void cfgpp_igemm_set_autotune(int on);
 void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x320 tiles (default) */
 void cfgpp_igemm_set_staged_epilogue(int on); /* 1 = LDS-transposed row-coalesced store epilogue (default) */
