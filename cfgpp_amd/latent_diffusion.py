@@ -21,26 +21,14 @@ import torch
 from . import coeffs as K
 from ._lib import CfgppError
 from .conditioning import SyntheticTextEncoder, as_list
+from .registry import Registry
 from .schedule import SchedulerTables, get_ancestral_step, get_sigmas_karras  # noqa: F401
 from .unet_config import SD15, UNetConfig
 
-####### Factory #######
-__SOLVER__: Dict[str, type] = {}
-
-
-def register_solver(name: str):
-    def wrapper(cls):
-        if __SOLVER__.get(name, None) is not None:
-            raise ValueError(f"Solver {name} already registered.")
-        __SOLVER__[name] = cls
-        return cls
-    return wrapper
-
-
-def get_solver(name: str, **kwargs):
-    if name not in __SOLVER__:
-        raise ValueError(f"Solver {name} does not exist.")
-    return __SOLVER__[name](**kwargs)
+# ---- solver registry (names: Appendix A of SURVEY.md) ----
+__SOLVER__ = Registry("Solver")
+register_solver = __SOLVER__.register        # @register_solver(name)
+get_solver = __SOLVER__.create               # get_solver(name, solver_config=..., device=..., **kw)
 
 
 class _SchedulerView:
@@ -358,9 +346,7 @@ class StableDiffusion:
         return den, x
 
 
-###########################################
-# Base version
-###########################################
+# ======== plain-CFG solvers (eps_hat used for both the x0 estimate and the renoising) ========
 def _sd_prompts(prompt):
     return prompt
 
@@ -459,9 +445,7 @@ class EditWordSwapDDIM(InversionDDIM):
         return self._finish(z0t)
 
 
-###########################################
-# CFG++ version
-###########################################
+# ======== CFG++ solvers (renoise with eps_uc; small-lambda regime) ========
 @register_solver("ddim_cfg++")
 class BaseDDIMCFGpp(BaseDDIM):
     """DDIM with CFG++: renoise with eps_uc (reference: latent_diffusion.py:621-679)."""

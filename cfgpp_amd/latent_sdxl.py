@@ -14,29 +14,17 @@ from typing import Any, Dict, Optional, Tuple
 
 import torch
 
+from .registry import Registry
 from . import coeffs as K
 from .conditioning import SyntheticTextEncoder, as_list
 from .latent_diffusion import StableDiffusion, _progress
 from .schedule import get_sigmas_karras
 from .unet_config import SDXL as SDXL_CFG
 
-####### Factory #######
-__SOLVER__: Dict[str, type] = {}
-
-
-def register_solver(name: str):
-    def wrapper(cls):
-        if __SOLVER__.get(name, None) is not None:
-            raise ValueError(f"Solver {name} already registered.")
-        __SOLVER__[name] = cls
-        return cls
-    return wrapper
-
-
-def get_solver(name: str, **kwargs):
-    if name not in __SOLVER__:
-        raise ValueError(f"Solver {name} does not exist.")
-    return __SOLVER__[name](**kwargs)
+# ---- solver registry (names: Appendix A of SURVEY.md) ----
+__SOLVER__ = Registry("Solver")
+register_solver = __SOLVER__.register        # @register_solver(name)
+get_solver = __SOLVER__.create               # get_solver(name, solver_config=..., device=..., **kw)
 
 
 class SDXL(StableDiffusion):
@@ -268,9 +256,7 @@ class SDXLLightning(SDXL):
         SDXL.__init__(self, solver_config, model_key=base_model_key, dtype=dtype, device=device, **kwargs)
 
 
-###########################################
-# Base version
-###########################################
+# ======== plain-CFG solvers (eps_hat used for both the x0 estimate and the renoising) ========
 @register_solver("ddim")
 class BaseDDIM(SDXL):
     """reference: latent_sdxl.py:425-467."""
@@ -359,9 +345,7 @@ class EditWardSwapDDIM(BaseDDIM):
                              callback_fn, wrap=False, zt=zt)
 
 
-###########################################
-# CFG++ version
-###########################################
+# ======== CFG++ solvers (renoise with eps_uc; small-lambda regime) ========
 @register_solver("ddim_cfg++")
 class BaseDDIMCFGpp(BaseDDIM):
     """reference: latent_sdxl.py:713-755."""
