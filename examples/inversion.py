@@ -29,22 +29,21 @@ def load_img(img_path, size: int = 512) -> torch.Tensor:
     return (torch.from_numpy(arr).permute(2, 0, 1) / 127.5 - 1.0).unsqueeze(0)
 
 
+# (flag, type, default) - the reference CLI's flags with its defaults, then ours
+REFERENCE_FLAGS = (
+    ("workdir", Path, Path("examples/workdir/inversion")), ("img_path", Path, Path("examples/assets/afhq_1.jpg")),
+    ("img_size", int, 512), ("device", str, "cuda"), ("null_prompt", str, ""), ("prompt", str, ""),
+    ("cfg_guidance", float, 7.5), ("method", str, "ddim_inversion_cfg++"), ("NFE", int, 10), ("seed", int, 42),
+)
+EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None))
+
+
 def main(argv=None, solver_kwargs=None) -> None:
     """``solver_kwargs`` lets tests inject ``engine=`` / ``vae=`` (CPU mock); the CLI never passes it."""
-    ap = argparse.ArgumentParser(description="Latent Diffusion inversion (CFG++) on MI355X")
-    ap.add_argument("--workdir", type=Path, default=Path("examples/workdir/inversion"))
-    ap.add_argument("--img_path", type=Path, default=Path("examples/assets/afhq_1.jpg"))
-    ap.add_argument("--img_size", type=int, default=512)
-    ap.add_argument("--device", type=str, default="cuda")
-    ap.add_argument("--null_prompt", type=str, default="")
-    ap.add_argument("--prompt", type=str, default="")
-    ap.add_argument("--cfg_guidance", type=float, default=7.5)
-    ap.add_argument("--method", type=str, default="ddim_inversion_cfg++")
-    ap.add_argument("--model", type=str, default="sd15", choices=["sd15", "sd20", "sdxl"])
-    ap.add_argument("--NFE", type=int, default=10)
-    ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--unet_weights", type=str, default="synthetic")
-    ap.add_argument("--vae_weights", type=str, default=None)
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    for flag, kind, default in REFERENCE_FLAGS + EXTRA_FLAGS:
+        ap.add_argument(f"--{flag}", type=kind, default=default)
+    ap.add_argument("--model", default="sd15", choices=("sd15", "sd20", "sdxl"))
     args = ap.parse_args(argv)
 
     from cfgpp_amd.callback_util import save_image

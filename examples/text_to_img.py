@@ -24,21 +24,21 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+# (flag, type, default) - the reference CLI's flags with its defaults, then ours
+REFERENCE_FLAGS = (
+    ("workdir", Path, Path("examples/workdir/t2i")), ("device", str, "cuda"),
+    ("null_prompt", str, "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,"), ("prompt", str, ""),
+    ("cfg_guidance", float, 7.5), ("method", str, "ddim"), ("NFE", int, 50), ("seed", int, 42),
+)
+EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("batch", int, 1))
+
+
 def main(argv=None, solver_kwargs=None) -> None:
     """``solver_kwargs`` lets tests inject ``engine=`` / ``vae=`` (CPU mock); the CLI never passes it."""
-    ap = argparse.ArgumentParser(description="Latent Diffusion (CFG++) on MI355X")
-    ap.add_argument("--workdir", type=Path, default=Path("examples/workdir/t2i"))
-    ap.add_argument("--device", type=str, default="cuda")
-    ap.add_argument("--null_prompt", type=str, default="low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,")
-    ap.add_argument("--prompt", type=str, default="")
-    ap.add_argument("--cfg_guidance", type=float, default=7.5)
-    ap.add_argument("--method", type=str, default="ddim")
-    ap.add_argument("--model", type=str, default="sd15", choices=["sd15", "sd20", "sdxl", "sdxl_lightning"])
-    ap.add_argument("--NFE", type=int, default=50)
-    ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--unet_weights", type=str, default="synthetic")
-    ap.add_argument("--vae_weights", type=str, default=None)
-    ap.add_argument("--batch", type=int, default=1)
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    for flag, kind, default in REFERENCE_FLAGS + EXTRA_FLAGS:
+        ap.add_argument(f"--{flag}", type=kind, default=default)
+    ap.add_argument("--model", default="sd15", choices=("sd15", "sd20", "sdxl", "sdxl_lightning"))
     ap.add_argument("--draw", action="store_true", help="save z0t / zt decodes every step (draw_tweedie + draw_noisy)")
     args = ap.parse_args(argv)
 
