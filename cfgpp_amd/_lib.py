@@ -41,6 +41,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 PROTOTYPES = {
     "cfgpp_last_error": (C.c_char_p, []),
     "cfgpp_step_ddim": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
+    "cfgpp_step_ddim_h": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
     "cfgpp_kdiff_input": (_I, [_P, _P, _F, _I, _L, _P]),
     "cfgpp_step_kdiff": (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_float), _I, _I, _I, _I, _L, _P]),
     "cfgpp_kdiff_denoise": (_I, [_P, _P, _P, _F, _F, _P, _P, _L, _P]),

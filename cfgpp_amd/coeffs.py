@@ -9,8 +9,9 @@ rule that is not visible in the formulas:
 
   a 0-dim fp32 *tensor* written FIRST in ``s * x`` with x fp16 is rounded to
   fp16 before the multiply on the torch-CPU path the golden vectors were
-  recorded on (``scalar_semantics="cpu"``, default);  torch-CUDA keeps it in
-  fp32 (``scalar_semantics="cuda"``).
+  recorded on (``scalar_semantics="cpu"``);  torch-CUDA - what the reference
+  actually runs on - passes a CPU 0-dim scalar to the kernel as an fp32
+  opmath value (``scalar_semantics="cuda"``, the default of the HIP engine).
 
 Reference lines: latent_diffusion.py:655-666, 901-908, 849-866; latent_sdxl.py:732-744, 892-919.
 """
@@ -41,11 +42,13 @@ def ddim_coeffs(a_tweedie, a_renoise, eps_half: bool = True, semantics: str = "c
     return (_first(c1, eps_half, semantics), float(c2), float(c3), _first(c4, eps_half, semantics))
 
 
-def ddim_coeffs_pinned(sqrt4, eps_half: bool = True, semantics: str = "cpu"):
+def ddim_coeffs_pinned(sqrt4, eps_half: bool = True, semantics: str = "cpu", z_half: bool = False):
     """Same as :func:`ddim_coeffs` but from the pinned sqrt tables
-    (``SchedulerTables.ddim_sqrt_coeffs``) - bit-stable across hosts."""
+    (``SchedulerTables.ddim_sqrt_coeffs``) - bit-stable across hosts.  ``z_half``: the latent itself is
+    fp16 (inversion / edit paths), so ``at_prev.sqrt() * z0t`` is another scalar-first product with an
+    fp16 tensor (c3); the divisor ``/ at.sqrt()`` (c2, scalar second) stays fp32 on every backend."""
     c1, c2, c3, c4 = (_s(v) for v in sqrt4)
-    return (_first(c1, eps_half, semantics), float(c2), float(c3), _first(c4, eps_half, semantics))
+    return (_first(c1, eps_half, semantics), float(c2), _first(c3, z_half, semantics), _first(c4, eps_half, semantics))
 
 
 def kdiff_input_scale_sd(sigma) -> float:

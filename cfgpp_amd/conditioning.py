@@ -102,9 +102,15 @@ class ClipTextTower:
         return cls(1280, kw.pop("layers", 32), 20, 5120, "gelu", 1280, True, 0, **kw)
 
     @torch.no_grad()
-    def __call__(self, prompts: List[str]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    def __call__(self, prompts: List[str], clip_skip: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """``clip_skip`` (SDXL only): ``hidden_states[-(clip_skip + 2)]`` instead of ``[-2]`` (latent_sdxl.py:88-92)."""
         ids = self.tok(prompts).to(self.device)
         out = self.model(input_ids=ids, output_hidden_states=True)
-        hs = out.hidden_states[-2] if self.penultimate else out.last_hidden_state
+        if clip_skip is not None:
+            if not self.penultimate:
+                raise NotImplementedError("clip_skip is defined for the SDXL (penultimate-layer) towers only")
+            hs = out.hidden_states[-(int(clip_skip) + 2)]
+        else:
+            hs = out.hidden_states[-2] if self.penultimate else out.last_hidden_state
         pooled = out.text_embeds if self.proj else None
         return hs.to(torch.float16), (None if pooled is None else pooled.to(torch.float16))

@@ -77,6 +77,39 @@ ddim_step_kernel(float* __restrict__ z, float* __restrict__ z0t_out,
     }
 }
 
+// fp16 LATENT variant: the inversion / edit paths start from `vae.encode(...)`, which is fp16 under the
+// reference's fp16 pipeline, so zt stays fp16 through the inversion AND the regeneration loop and every op
+// rounds to fp16 (latent_diffusion.py:168-180,527-541; latent_sdxl.py:307-318,989-1011):
+//     pa = h(c1*A); z0t = h(h(z - pa)/c2); z' = h(h(c3*z0t) + h(c4*B))
+__global__ void __launch_bounds__(256)
+ddim_step_h_kernel(half_t* __restrict__ z, half_t* __restrict__ z0t_out,
+                   const half_t* __restrict__ eps_uc, const half_t* __restrict__ eps_c,
+                   float lam, float c1, float c2, float c3, float c4,
+                   int tweedie_uc, int renoise_uc, long n4) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const half4_t zv = reinterpret_cast<const half4_t*>(z)[i];
+        const half4_t a = reinterpret_cast<const half4_t*>(eps_uc)[i];
+        const half4_t b = reinterpret_cast<const half4_t*>(eps_c)[i];
+        half4_t z0, zn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float uc = (float)a[k], cc = (float)b[k];
+            const float hat = cfg_mix_h(uc, cc, lam);
+            const float A = tweedie_uc ? uc : hat;
+            const float B = renoise_uc ? uc : hat;
+            const float pa = h_round(__fmul_rn(A, c1));
+            const float pb = h_round(__fmul_rn(B, c4));
+            const float z0f = h_round(__fdiv_rn(h_round(__fsub_rn((float)zv[k], pa)), c2));
+            const float znf = h_round(__fadd_rn(h_round(__fmul_rn(c3, z0f)), pb));
+            z0[k] = (half_t)z0f; zn[k] = (half_t)znf;
+        }
+        reinterpret_cast<half4_t*>(z0t_out)[i] = z0;
+        reinterpret_cast<half4_t*>(z)[i] = zn;
+    }
+}
+
 // scale the k-diffusion latent into the UNet input: xc = x / s (SD1.5, mode 0) or x * s (SDXL 2M, mode 1)
 __global__ void __launch_bounds__(256)
 kdiff_input_kernel(const half_t* __restrict__ x, half_t* __restrict__ xc, float s, int mode, long n) {
@@ -202,6 +235,18 @@ int cfgpp_step_ddim(void* z, void* z0t_out, const void* eps_uc, const void* eps_
     else
         hipLaunchKernelGGL(ddim_step_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, s, (float*)z, (float*)z0t_out,
                            eps_uc, eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int cfgpp_step_ddim_h(void* z, void* z0t_out, const void* eps_uc, const void* eps_c,
+                      float lam, float c1, float c2, float c3, float c4,
+                      int tweedie_uc, int renoise_uc, long n, void* stream) {
+    CFGPP_REQUIRE(n > 0 && (n % 4) == 0, "cfgpp_step_ddim_h: n=%ld must be a positive multiple of 4", n);
+    CFGPP_REQUIRE(z && z0t_out && eps_uc && eps_c, "cfgpp_step_ddim_h: null pointer");
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(ddim_step_h_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (half_t*)z, (half_t*)z0t_out,
+                       (const half_t*)eps_uc, (const half_t*)eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

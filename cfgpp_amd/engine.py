@@ -26,7 +26,10 @@ def _require_cuda(t: torch.Tensor, name: str):
         raise CfgppError(f"{name} must be contiguous")
 
 
-def _stream_ptr() -> int:
+def _stream_ptr(t: Optional[torch.Tensor] = None) -> int:
+    """the current torch stream of the device the tensor lives on (not of whatever device is current)"""
+    if t is not None and t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -43,16 +46,23 @@ def step_ddim(z: torch.Tensor, z0t_out: torch.Tensor, eps_uc: torch.Tensor, eps_
     lib = _lib.load()
     for n, t in (("z", z), ("z0t_out", z0t_out), ("eps_uc", eps_uc), ("eps_c", eps_c)):
         _require_cuda(t, n)
-    if z.dtype != torch.float32 or z0t_out.dtype != torch.float32:
-        raise CfgppError("step_ddim: z and z0t_out must be fp32")
+    if z.dtype != z0t_out.dtype or z.dtype not in (torch.float16, torch.float32):
+        raise CfgppError("step_ddim: z and z0t_out must both be fp32 or both fp16")
     if eps_uc.dtype != eps_c.dtype or eps_uc.dtype not in (torch.float16, torch.float32):
         raise CfgppError("step_ddim: eps must both be fp16 or both fp32")
     if not (z.numel() == z0t_out.numel() == eps_uc.numel() == eps_c.numel()):
         raise CfgppError("step_ddim: size mismatch")
     c1, c2, c3, c4 = (float(x) for x in coeffs)
+    if z.dtype == torch.float16:          # fp16 latent (inversion / edit paths): every op rounds to fp16
+        if eps_uc.dtype != torch.float16:
+            raise CfgppError("step_ddim: an fp16 latent needs fp16 eps")
+        check(lib.cfgpp_step_ddim_h(z.data_ptr(), z0t_out.data_ptr(), eps_uc.data_ptr(), eps_c.data_ptr(), float(lam),
+                                    c1, c2, c3, c4, int(bool(tweedie_uc)), int(bool(renoise_uc)), z.numel(), _stream_ptr(z)),
+              "cfgpp_step_ddim_h")
+        return
     check(lib.cfgpp_step_ddim(z.data_ptr(), z0t_out.data_ptr(), eps_uc.data_ptr(), eps_c.data_ptr(),
                               1 if eps_uc.dtype == torch.float16 else 0, float(lam), c1, c2, c3, c4,
-                              int(bool(tweedie_uc)), int(bool(renoise_uc)), z.numel(), _stream_ptr()),
+                              int(bool(tweedie_uc)), int(bool(renoise_uc)), z.numel(), _stream_ptr(z)),
           "cfgpp_step_ddim")
 
 
@@ -62,7 +72,7 @@ def kdiff_input(x: torch.Tensor, xc_out: torch.Tensor, s: float, mode: int):
     _require_cuda(xc_out, "xc_out")
     if x.dtype != torch.float16 or xc_out.dtype != torch.float16:
         raise CfgppError("kdiff_input: fp16 latents expected")
-    check(lib.cfgpp_kdiff_input(x.data_ptr(), xc_out.data_ptr(), float(s), int(mode), x.numel(), _stream_ptr()),
+    check(lib.cfgpp_kdiff_input(x.data_ptr(), xc_out.data_ptr(), float(s), int(mode), x.numel(), _stream_ptr(x)),
           "cfgpp_kdiff_input")
 
 
@@ -78,7 +88,7 @@ def step_kdiff(x: torch.Tensor, den_out: torch.Tensor, old: Optional[torch.Tenso
     arr = (C.c_float * 9)(*[float(v) for v in coef9])
     check(lib.cfgpp_step_kdiff(x.data_ptr(), den_out.data_ptr(), _ptr(old), eps_uc.data_ptr(), eps_c.data_ptr(),
                                arr, int(variant), int(bool(xl_form)), int(bool(euler_branch)), int(bool(write_old)),
-                               x.numel(), _stream_ptr()), "cfgpp_step_kdiff")
+                               x.numel(), _stream_ptr(x)), "cfgpp_step_kdiff")
 
 
 def kdiff_denoise(x, eps_uc, eps_c, lam: float, sigma: float, den_out, uden_out):
@@ -88,7 +98,7 @@ def kdiff_denoise(x, eps_uc, eps_c, lam: float, sigma: float, den_out, uden_out)
         if t.dtype != torch.float16:
             raise CfgppError(f"kdiff_denoise: {n} must be fp16")
     check(lib.cfgpp_kdiff_denoise(x.data_ptr(), eps_uc.data_ptr(), eps_c.data_ptr(), float(lam), float(sigma),
-                                  den_out.data_ptr(), uden_out.data_ptr(), x.numel(), _stream_ptr()), "cfgpp_kdiff_denoise")
+                                  den_out.data_ptr(), uden_out.data_ptr(), x.numel(), _stream_ptr(x)), "cfgpp_kdiff_denoise")
 
 
 def lincomb(out, x, y, z, a: float, b: float, mode: int):
@@ -98,7 +108,7 @@ def lincomb(out, x, y, z, a: float, b: float, mode: int):
         if t.dtype != torch.float16:
             raise CfgppError(f"lincomb: {n} must be fp16")
     check(lib.cfgpp_lincomb(out.data_ptr(), x.data_ptr(), y.data_ptr(), _ptr(z), float(a), float(b), int(mode), x.numel(),
-                            _stream_ptr()), "cfgpp_lincomb")
+                            _stream_ptr(x)), "cfgpp_lincomb")
 
 
 # ----------------------------------------------------------------------------
@@ -194,7 +204,7 @@ class HipUNet:
         self._keep["ctx"] = (ehs, te, ti)
         self.rows = rows
         check(self.lib.cfgpp_unet_set_context(self._h, ehs.data_ptr(), rows, tokens, _ptr(te), _ptr(ti), cond_rows,
-                                              _stream_ptr()), "cfgpp_unet_set_context")
+                                              _stream_ptr(ehs)), "cfgpp_unet_set_context")
 
     # -- forward -----------------------------------------------------------------
     def forward(self, z: torch.Tensor, t: float, eps_out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -211,7 +221,7 @@ class HipUNet:
         if eps_out is None:
             eps_out = torch.empty((rows, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=z.device)
         check(self.lib.cfgpp_unet_forward(self._h, z.data_ptr(), 1 if z.dtype == torch.float16 else 0, zr, float(t),
-                                          eps_out.data_ptr(), rows, _stream_ptr()), "cfgpp_unet_forward")
+                                          eps_out.data_ptr(), rows, _stream_ptr(z)), "cfgpp_unet_forward")
         return eps_out
 
     def profile(self, z: torch.Tensor, t: float, detail: bool = False) -> dict:
@@ -222,7 +232,7 @@ class HipUNet:
         ms, fl, ln = (C.c_double * 4)(), (C.c_double * 4)(), (C.c_int * 4)()
         buf = C.create_string_buffer(1 << 20) if detail else None
         check(self.lib.cfgpp_unet_profile(self._h, z.data_ptr(), 1 if z.dtype == torch.float16 else 0, int(z.shape[0]),
-                                          float(t), eps.data_ptr(), rows, _stream_ptr(), ms, fl, ln, buf, (1 << 20) if detail else 0),
+                                          float(t), eps.data_ptr(), rows, _stream_ptr(z), ms, fl, ln, buf, (1 << 20) if detail else 0),
               "cfgpp_unet_profile")
         names = ("igemm", "attention", "norm", "small")
         out = {n: dict(ms=ms[i], flops=fl[i], launches=ln[i]) for i, n in enumerate(names)}

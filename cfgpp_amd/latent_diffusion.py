@@ -60,7 +60,10 @@ class StableDiffusion:
         self.device = device
         self.model_key = model_key
         self.dtype = kwargs.get("pipe_dtype", torch.float16)
-        self.scalar_semantics = kwargs.get("scalar_semantics", "cpu")
+        # how a 0-dim fp32 scalar written first in `s * fp16_tensor` enters the product (coeffs.py): the
+        # reference RUNS on the GPU, where torch keeps it fp32 ("cuda"); the golden vectors were recorded on
+        # torch-CPU, which rounds it to fp16 first ("cpu": the default only when a test injects an engine).
+        self.scalar_semantics = kwargs.get("scalar_semantics", "cpu" if kwargs.get("engine") is not None else "cuda")
         cfg = kwargs.get("unet_config", self.unet_config)
         self.cfg = cfg
         self.latent_hw = tuple(kwargs.get("latent_hw", (cfg.sample_size, cfg.sample_size)))
@@ -123,8 +126,10 @@ class StableDiffusion:
         return self.vae
 
     def encode(self, x):
-        """xt -> zt (posterior sample * scale; latent_diffusion.py:117-121)."""
-        return self._get_vae().encode(x.to(self.work_device))
+        """xt -> zt (posterior sample * scale; latent_diffusion.py:117-121).  The reference's VAE runs in
+        ``pipe_dtype`` (fp16), so the latent it returns - and with it the whole inversion / edit chain - is
+        fp16; the HIP encoder's fp32 posterior sample is rounded to that dtype here."""
+        return self._get_vae().encode(x.to(self.work_device)).to(self.dtype)
 
     def decode(self, zt):
         """zt -> xt (latent_diffusion.py:123-129)."""
@@ -137,7 +142,7 @@ class StableDiffusion:
             raise ValueError("predict_noise needs at least one of uc / c")
         a = c if uc is None else uc
         b = uc if c is None else c
-        key = (a.data_ptr(), b.data_ptr(), tuple(a.shape), tuple(b.shape))
+        key = (a.data_ptr(), b.data_ptr(), tuple(a.shape), tuple(b.shape), a._version, b._version)
         if getattr(self, "_ctx_key", None) != key:
             self._set_context(a, b)
             self._ctx_key = key
@@ -201,8 +206,15 @@ class StableDiffusion:
 
     # ------------------------------------------------------------------ fused loops
     def _ddim_update(self, zt, z0t, noise_uc, noise_c, lam, sqrt4, tweedie_uc, renoise_uc):
-        co = K.ddim_coeffs_pinned(sqrt4, eps_half=(noise_uc.dtype == torch.float16), semantics=self.scalar_semantics)
+        co = K.ddim_coeffs_pinned(sqrt4, eps_half=(noise_uc.dtype == torch.float16), semantics=self.scalar_semantics,
+                                  z_half=(zt.dtype == torch.float16))
         self.engine.step_ddim(zt, z0t, noise_uc, noise_c, lam, co, tweedie_uc, renoise_uc)
+
+    def _own_latent(self, z):
+        """private, contiguous copy on the engine device (the loops update it in place); fp16 stays fp16
+        (the reference's inversion / edit latents), everything else runs as fp32 like ``torch.randn``."""
+        dt = torch.float16 if z.dtype == torch.float16 else torch.float32
+        return z.detach().to(device=self.work_device, dtype=dt, copy=True).contiguous()
 
     def _run_callback(self, callback_fn, step, t, z0t, zt):
         kw = callback_fn(step, t, {"z0t": z0t.detach(), "zt": zt.detach(), "decode": self.decode})
@@ -213,8 +225,9 @@ class StableDiffusion:
 
     def _ddim_forward(self, zt, uc, c, cfg_guidance, cfgpp: bool, callback_fn=None, desc="SD", wrap_index=False):
         """DDIM / DDIM-CFG++ reverse loop (latent_diffusion.py:272-294 / 652-674).
-        ``zt`` fp32 [B,4,H,W] on the engine device, updated in place; returns (z0t, zt)."""
-        zt = zt.to(torch.float32).contiguous()
+        ``zt`` [B,4,H,W] on the engine device: fp32 (text-to-image: ``torch.randn``) or fp16 (after an
+        inversion that started from the fp16 VAE latent); a private copy is updated in place; returns (z0t, zt)."""
+        zt = self._own_latent(zt)
         z0t = torch.empty_like(zt)
         ts = self.scheduler.timesteps
         ts = ts.int() if wrap_index else ts
@@ -230,7 +243,7 @@ class StableDiffusion:
 
     def _ddim_inversion(self, z0, uc, c, cfg_guidance, cfgpp: bool):
         """DDIM inversion (latent_diffusion.py:160-182 CFG, 888-910 CFG++)."""
-        zt = z0.clone().to(self.work_device).to(torch.float32).contiguous()
+        zt = self._own_latent(z0)
         z0t = torch.empty_like(zt)
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM Inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)     # a_tw = alpha(t-skip), a_rn = alpha(t)

@@ -49,7 +49,17 @@ class SDXL(StableDiffusion):
     # ------------------------------------------------------------------ text
     @torch.no_grad()
     def _text_embed(self, prompt, encoder, clip_skip=None):
-        hs, pooled = encoder(as_list(prompt))
+        """reference: latent_sdxl.py:76-93.  ``clip_skip`` selects ``hidden_states[-(clip_skip + 2)]`` there; an
+        encoder that exposes its hidden states takes it as a keyword, one that cannot honour it must not
+        silently ignore it."""
+        if clip_skip is None:
+            hs, pooled = encoder(as_list(prompt))
+        else:
+            try:
+                hs, pooled = encoder(as_list(prompt), clip_skip=int(clip_skip))
+            except TypeError as e:
+                raise NotImplementedError(f"clip_skip={clip_skip}: text encoder {type(encoder).__name__} returns one "
+                                          "hidden state only (no clip_skip keyword)") from e
         return hs, pooled
 
     @torch.no_grad()
@@ -86,7 +96,8 @@ class SDXL(StableDiffusion):
         a = c if uc is None else uc
         b = uc if c is None else c
         te, ti = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
-        key = (a.data_ptr(), b.data_ptr(), te.data_ptr(), ti.data_ptr(), tuple(te.shape), tuple(a.shape), tuple(b.shape))
+        key = (a.data_ptr(), b.data_ptr(), te.data_ptr(), ti.data_ptr(), tuple(te.shape), tuple(a.shape), tuple(b.shape),
+               a._version, b._version, te._version, ti._version)
         if getattr(self, "_ctx_key", None) != key:
             B = max(int(a.shape[0]), int(b.shape[0]))
             rows = 2 * B
@@ -177,13 +188,20 @@ class SDXL(StableDiffusion):
 
     def _split_cond_for_inversion(self, cfg_guidance, add_cond_kwargs):
         # lambda in {0,1}: add_cond_kwargs is reduced IN PLACE to its last row (latent_sdxl.py:302-305)
+        # batch extension: the reference is batch-1, where "[-1]" is THE positive row; with B chains the
+        # positive rows are the last B ([neg_1..neg_B, pos_1..pos_B] or already [pos_1..pos_B])
         if cfg_guidance == 0.0 or cfg_guidance == 1.0:
-            add_cond_kwargs["text_embeds"] = add_cond_kwargs["text_embeds"][-1].unsqueeze(0)
-            add_cond_kwargs["time_ids"] = add_cond_kwargs["time_ids"][-1].unsqueeze(0)
+            B = getattr(self, "_batch", 1)
+            if B <= 1:
+                add_cond_kwargs["text_embeds"] = add_cond_kwargs["text_embeds"][-1].unsqueeze(0)
+                add_cond_kwargs["time_ids"] = add_cond_kwargs["time_ids"][-1].unsqueeze(0)
+            else:
+                add_cond_kwargs["text_embeds"] = add_cond_kwargs["text_embeds"][-B:]
+                add_cond_kwargs["time_ids"] = add_cond_kwargs["time_ids"][-B:]
 
     def _inversion_xl(self, z0, uc, c, cfg_guidance, add_cond_kwargs, cfgpp):
         self._split_cond_for_inversion(cfg_guidance, add_cond_kwargs)
-        zt = z0.clone().to(self.work_device).to(torch.float32).contiguous()
+        zt = self._own_latent(z0)
         z0t = torch.empty_like(zt)
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)
@@ -206,7 +224,7 @@ class SDXL(StableDiffusion):
                  seeds=None):
         if zt is None:
             zt = self.initialize_latent(size=self._latent_size(shape), seeds=seeds)
-        zt = zt.to(self.work_device).to(torch.float32).contiguous()
+        zt = self._own_latent(zt)
         z0t = torch.empty_like(zt)
         ts = self.scheduler.timesteps.int() if wrap else self.scheduler.timesteps
         for step, t in enumerate(_progress(ts, desc)):

@@ -39,6 +39,14 @@ int cfgpp_step_ddim(void* z, void* z0t_out, const void* eps_uc, const void* eps_
                     float lam, float c1, float c2, float c3, float c4,
                     int tweedie_uc, int renoise_uc, long n, void* stream);
 
+/* The same update on n fp16 latent elements (z, z0t_out and both eps fp16), every op rounded to
+ * fp16: the reference's inversion / edit paths, whose latent starts as the fp16 `vae.encode(...)`
+ * sample and therefore stays fp16 through `inversion()` and the regeneration loop
+ * (latent_diffusion.py:168-180,527-541,901-908; latent_sdxl.py:307-318,966-1011). */
+int cfgpp_step_ddim_h(void* z, void* z0t_out, const void* eps_uc, const void* eps_c,
+                      float lam, float c1, float c2, float c3, float c4,
+                      int tweedie_uc, int renoise_uc, long n, void* stream);
+
 /* k-diffusion UNet input scaling on fp16 latents: mode 0: xc = x / s
  * (latent_diffusion.py:229-230, s = sqrt(sigma^2+1)); mode 1: xc = x * s (latent_sdxl.py:901). */
 int cfgpp_kdiff_input(const void* x, void* xc, float s, int mode, long n, void* stream);

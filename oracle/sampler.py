@@ -60,7 +60,7 @@ def cfg_mix(eps_uc: torch.Tensor, eps_c: torch.Tensor, lam: float) -> torch.Tens
     return eps_uc + d * _s(lam)
 
 
-def _smul_first(s, x: torch.Tensor) -> torch.Tensor:
+def _smul_first(s, x: torch.Tensor, semantics: str = "cpu") -> torch.Tensor:
     """``s * x`` with the 0-dim fp32 TENSOR scalar written FIRST, as the reference
     writes ``(1-at).sqrt() * noise_pred`` or ``-torch.exp(-h) * uncond_denoised``.
 
@@ -69,16 +69,18 @@ def _smul_first(s, x: torch.Tensor) -> torch.Tensor:
     common dtype, i.e. ROUNDED TO FP16; the product is then formed in fp32 and
     rounded once.  (torch-CUDA keeps the scalar in fp32 here: the HIP kernel takes
     fp32 coefficients and the host chooses whether to pre-round them - see
-    ``cfgpp_amd.coeffs``.)  Result keeps x's dtype."""
+    ``cfgpp_amd.coeffs``.)  ``semantics="cuda"`` restates that GPU behaviour: the scalar enters the product as
+    an fp32 opmath value.  It is what the product runs with by default, and it is NOT pinned by golden vectors
+    (they can only be recorded on torch-CPU here).  Result keeps x's dtype."""
     s = _s(s)
     if x.dtype == H:
-        return _h(_f(x) * _f(_h(s)))
+        return _h(_f(x) * (_f(_h(s)) if semantics == "cpu" else s))
     return x * s
 
 
-def _scale_eps(coef: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+def _scale_eps(coef: torch.Tensor, eps: torch.Tensor, semantics: str = "cpu") -> torch.Tensor:
     """``coef * eps`` (scalar first), returned as fp32 for the fp32 latent update."""
-    return _f(_smul_first(coef, eps))
+    return _f(_smul_first(coef, eps, semantics))
 
 
 # ----------------------------------------------------------------------------
@@ -91,7 +93,8 @@ def ddim_coeffs(a_tweedie, a_renoise):
     return (1 - a_tw).sqrt(), a_tw.sqrt(), a_rn.sqrt(), (1 - a_rn).sqrt()
 
 
-def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, renoise_uc: bool, sqrt4=None):
+def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, renoise_uc: bool, sqrt4=None,
+              semantics: str = "cpu"):
     """One generalised DDIM update.
 
         z0t = (z - sqrt(1-a_tw) * A) / sqrt(a_tw)
@@ -102,7 +105,12 @@ def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, ren
     inversion CFG  : a_tw=alpha(t-skip), a_rn=alpha(t),      A=eps_hat, B=eps_hat
     inversion CFG++: a_tw=alpha(t-skip), a_rn=alpha(t),      A=eps_uc,  B=eps_hat
 
-    z is fp32; z0t and z' are fp32 (fp16 eps products are rounded to fp16 first).
+    z fp32 (text-to-image: ``torch.randn``): z0t and z' are fp32 (fp16 eps products are rounded to fp16 first).
+    z fp16 (inversion / edit: the latent is the fp16 ``vae.encode`` sample, latent_diffusion.py:168,527-541;
+    latent_sdxl.py:307,989-1011): every op rounds to fp16 -
+        pa = h(c1*A); z0t = h(h(z - pa) / c2); z' = h(h(c3*z0t) + h(c4*B))
+    with the scalar-first products (c1, c3, c4) following ``semantics`` and the divisor c2 (scalar second)
+    fp32 on every backend (probed on torch-CPU; pinned by tests/golden/sampler_golden_h16.npz).
     ``sqrt4`` = (c1, c2, c3, c4) overrides the torch ``sqrt`` evaluation with pinned values
     (``torch.sqrt`` differs by 1 ulp between hosts; see cfgpp_amd/schedule.py).
     """
@@ -113,9 +121,14 @@ def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, ren
     eps_hat = cfg_mix(eps_uc, eps_c, lam)
     A = eps_uc if tweedie_uc else eps_hat
     B = eps_uc if renoise_uc else eps_hat
+    if z.dtype == H:
+        pa = _smul_first(c1, A, semantics)
+        z0t = _div_s(_sub(z, pa), c2)
+        zn = _add(_smul_first(c3, z0t, semantics), _smul_first(c4, B, semantics))
+        return z0t, zn
     zf = _f(z)
-    z0t = (zf - _scale_eps(c1, A)) / c2
-    zn = c3 * z0t + _scale_eps(c4, B)
+    z0t = (zf - _scale_eps(c1, A, semantics)) / c2
+    zn = c3 * z0t + _scale_eps(c4, B, semantics)
     return z0t, zn
 
 
@@ -230,12 +243,12 @@ def dpm2m_step(x, den, uden, old, sigmas, i, variant: str):
 # ----------------------------------------------------------------------------
 # whole-loop drivers (used by tests and by bench.py's cpu_baseline leg)
 # ----------------------------------------------------------------------------
-def sample_ddim(unet_fn, zT, tables, lam, cfgpp=True, wrap_index=False, callback_fn=None):
+def sample_ddim(unet_fn, zT, tables, lam, cfgpp=True, wrap_index=False, callback_fn=None, semantics: str = "cpu"):
     """DDIM / DDIM-CFG++ forward loop on fp32 latents.
 
     unet_fn(z, t) -> (eps_uc, eps_c).  ``wrap_index`` selects the SDXL unguarded
     index rule (quirk Q3).  Returns (z0t, zt, trajectory-less)."""
-    zt = zT.clone().to(F)
+    zt = zT.clone() if zT.dtype == H else zT.clone().to(F)
     z0t = None
     ts = tables.timesteps
     ts = ts.int() if wrap_index else ts
@@ -246,19 +259,19 @@ def sample_ddim(unet_fn, zT, tables, lam, cfgpp=True, wrap_index=False, callback
             at, at_prev = tables.alpha(t), tables.alpha(int(t) - tables.skip)
         eps_uc, eps_c = unet_fn(zt, t)
         z0t, zt = ddim_step(zt, eps_uc, eps_c, lam, at, at_prev, tweedie_uc=False, renoise_uc=cfgpp,
-                            sqrt4=tables.ddim_sqrt_coeffs(t, wrap=wrap_index))
+                            sqrt4=tables.ddim_sqrt_coeffs(t, wrap=wrap_index), semantics=semantics)
         if callback_fn is not None:
             kw = callback_fn(step, t, {"z0t": z0t, "zt": zt, "decode": None})
             z0t, zt = kw["z0t"], kw["zt"]
     return z0t, zt
 
 
-def invert_ddim(unet_fn, z0, tables, lam, cfgpp=True):
+def invert_ddim(unet_fn, z0, tables, lam, cfgpp=True, semantics: str = "cpu"):
     """DDIM inversion loop (latent_diffusion.py:888-910 / :160-182)."""
-    zt = z0.clone().to(F)
+    zt = z0.clone() if z0.dtype == H else z0.clone().to(F)
     for t in reversed(tables.timesteps):
         at, at_prev = tables.alpha(t), tables.alpha(int(t) - tables.skip)
         eps_uc, eps_c = unet_fn(zt, t)
         _, zt = ddim_step(zt, eps_uc, eps_c, lam, at_prev, at, tweedie_uc=cfgpp, renoise_uc=False,
-                          sqrt4=tables.ddim_sqrt_coeffs(t, inversion=True))
+                          sqrt4=tables.ddim_sqrt_coeffs(t, inversion=True), semantics=semantics)
     return zt

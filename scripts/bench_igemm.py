@@ -10,9 +10,12 @@ SHAPES = [  # name, kind, batch rows, HW side, Cin, Cout(N)
     ("lin_l0_320x320", "lin", 16, 64, 320, 320), ("lin_l0_qkv", "lin", 16, 64, 320, 960), ("lin_l0_geglu", "lin", 16, 64, 320, 2560),
     ("lin_l0_ffout", "lin", 16, 64, 1280, 320), ("lin_l1_geglu", "lin", 16, 32, 640, 5120), ("lin_l2_geglu", "lin", 16, 16, 1280, 10240),
     ("xl_geglu_32", "lin", 4, 32, 1280, 10240), ("xl_ffout_32", "lin", 4, 32, 5120, 1280), ("xl_qkv_32", "lin", 4, 32, 1280, 3840),
+    ("xl_lin_32_1280", "lin", 4, 32, 1280, 1280), ("xl_lin_64_640", "lin", 4, 64, 640, 640), ("xl_ffout_64", "lin", 4, 64, 2560, 640),
+    ("lin_l1_640x640", "lin", 16, 32, 640, 640), ("lin_l1_ffout", "lin", 16, 32, 2560, 640), ("lin_l1_qkv", "lin", 16, 32, 640, 1920),
+    ("lin_l2_1280", "lin", 16, 16, 1280, 1280), ("lin_l2_ffout", "lin", 16, 16, 5120, 1280), ("lin_l2_qkv", "lin", 16, 16, 1280, 3840),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,2,3,11,12,13").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,4,5,6,7,8,9").split(",")]
 iters = int(os.environ.get("ITERS", "20"))
 def timeit(fn):
     for _ in range(3): fn()

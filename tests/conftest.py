@@ -22,3 +22,15 @@ def golden():
     with open(os.path.join(ROOT, "tests", "golden", "sampler_golden.json")) as f:
         meta = json.load(f)
     return g, meta
+
+
+@pytest.fixture(scope="session")
+def golden_h16():
+    """inversion / edit trajectories recorded from the reference with an fp16 VAE (fp16 latents end to end)"""
+    import json
+
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sampler_golden_h16.npz"))
+    with open(os.path.join(ROOT, "tests", "golden", "sampler_golden_h16.json")) as f:
+        meta = json.load(f)
+    return g, meta

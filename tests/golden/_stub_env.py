@@ -130,6 +130,8 @@ class _LatentDist:
 class FakeVAE:
     """encode = 8x8 average pool of a fixed channel mix; decode = its adjoint-ish."""
 
+    latent_dtype = None      # set to torch.float16 to emulate the reference's fp16 VAE (its latents are fp16)
+
     def __init__(self, scaling_factor):
         self.config = _Cfg(scaling_factor=scaling_factor, block_out_channels=[128, 256, 512, 512],
                            force_upcast=False)
@@ -143,6 +145,8 @@ class FakeVAE:
         z = torch.nn.functional.avg_pool2d(xf, 8)
         mix = torch.tensor([[1.0, 0.2, -0.3], [0.1, 0.9, 0.4], [-0.5, 0.3, 0.8], [0.3, -0.6, 0.5]])
         z = torch.einsum("oc,bchw->bohw", mix, z) * 4.0
+        if FakeVAE.latent_dtype is not None:
+            z = z.to(FakeVAE.latent_dtype)
         return _Cfg(latent_dist=_LatentDist(z))
 
     def decode(self, z):

@@ -299,3 +299,23 @@ np.savez_compressed(os.path.join(HERE, "sampler_golden.npz"), **out)
 with open(os.path.join(HERE, "sampler_golden.json"), "w") as f:
     json.dump(meta, f, indent=1, sort_keys=True)
 print("wrote", len(out), "arrays;", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+# ----------------------------------------------------------------------------
+# G3h: the inversion / edit paths with an fp16 VAE, as the reference runs them (pipe_dtype = fp16: the
+# latent `vae.encode(...)` returns is fp16 and STAYS fp16 through inversion() and the regeneration loop,
+# every op rounding to fp16).  Separate file so that sampler_golden.npz keeps regenerating bit-identically.
+# ----------------------------------------------------------------------------
+out.clear()
+meta.clear()
+stub.FakeVAE.latent_dtype = torch.float16
+run_sd("ddim_inversion_cfg++", "G3h/sd_inv_cfgpp", 10, 0.6, src=True)
+run_sd("ddim_inversion", "G3h/sd_inv_cfg", 10, 2.0, src=True)
+run_sd("ddim_edit_cfg++", "G3h/sd_edit_cfgpp", 10, 0.6, src=True, prompts=[NULL, PROMPT, PROMPT2])
+run_xl("ddim_edit_cfg++", "G3h/xl_edit_cfgpp", 10, 0.6, src=True, prompts=[NULL, PROMPT, PROMPT2])
+run_xl("ddim_edit_cfg++", "G3h/xl_edit_cfgpp_recon", 10, 0.6, src=True, prompts=[NULL, PROMPT, PROMPT])
+run_xl("ddim_edit", "G3h/xl_edit_cfg", 10, 3.0, src=True, prompts=[NULL, PROMPT, PROMPT2])
+stub.FakeVAE.latent_dtype = None
+np.savez_compressed(os.path.join(HERE, "sampler_golden_h16.npz"), **out)
+with open(os.path.join(HERE, "sampler_golden_h16.json"), "w") as f:
+    json.dump(meta, f, indent=1, sort_keys=True)
+print("wrote", len(out), "fp16-latent arrays;", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")

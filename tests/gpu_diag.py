@@ -168,7 +168,7 @@ def t_big():
     wl = rnd(640, 256, scale=1 / 16, seed=86)
     bl = rnd(640, scale=0.1, seed=87)
     refl = a @ wl.t() + bl
-    for c in (4, 5, 6):
+    for c in (4, 5, 6, 7, 8, 9):     # 7 / 8: 128x160 / 128x320 (partial loader passes); 9: 128x160 with two k-groups
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
@@ -340,7 +340,7 @@ def t_step():
     return {"mismatching_elements": bad, "steps": int(len(tb.timesteps))}
 
 
-def unet_case(cfg_name, R, hw, seed=0, iters=0):
+def unet_case(cfg_name, R, hw, seed=0, iters=0, tvals=(981.0, 1.0)):
     from cfgpp_amd.engine import HipUNet
     from cfgpp_amd.unet_config import CONFIGS
     from cfgpp_amd.weights import synth_state_dict
@@ -362,11 +362,12 @@ def unet_case(cfg_name, R, hw, seed=0, iters=0):
     t_build = time.time() - t0
     net.set_context(ehs, te, ti)
     out = {}
-    for tval in (981.0, 1.0):
+    ref_net = UNetRef(cfg, sd)
+    for tval in tvals:
         eps = net.forward(z.to(H.DEV), tval)
         torch.cuda.synchronize()
         t0 = time.time()
-        ref = UNetRef(cfg, sd)(torch.cat([z, z]), tval, ehs, ack)["sample"]
+        ref = ref_net(torch.cat([z, z]), tval, ehs, ack)["sample"]
         out[f"t{int(tval)}"] = dict(H.err_stats(eps, ref), cpu_ref_s=round(time.time() - t0, 2))
     out["build_s"] = round(t_build, 1)
     out["device_GB"] = round(net.device_bytes() / 1e9, 2)

@@ -34,6 +34,14 @@ def emulate_step_ddim(z, z0t_out, eps_uc, eps_c, lam, coeffs, tweedie_uc, renois
     hat = O.cfg_mix(eps_uc, eps_c, lam)
     A = eps_uc if tweedie_uc else hat
     B = eps_uc if renoise_uc else hat
+    if z.dtype == H:        # fp16 latent: every op rounds to fp16 (ddim_step_h_kernel)
+        r = lambda t: _f(_h(t))  # noqa: E731
+        pa, pb = r(_f(A) * c1), r(_f(B) * c4)
+        z0 = r(r(_f(z) - pa) / c2)
+        zn = r(r(c3 * z0) + pb)
+        z0t_out.copy_(_h(z0))
+        z.copy_(_h(zn))
+        return
     if eps_uc.dtype == H:
         pa, pb = _f(_h(_f(A) * c1)), _f(_h(_f(B) * c4))
     else:

@@ -51,6 +51,48 @@ def test_ddim_steps_bit_exact(golden, tag, nfe, kind, lam, cfgpp, wrap):
         assert torch.equal(b, z[i + 1][0:1]), f"{tag} inversion step {i}"
 
 
+H16_CASES = [("G3h/sd_inv_cfgpp", 0.6, True), ("G3h/sd_inv_cfg", 2.0, False), ("G3h/sd_edit_cfgpp", 0.6, True),
+             ("G3h/xl_edit_cfgpp", 0.6, True), ("G3h/xl_edit_cfgpp_recon", 0.6, True), ("G3h/xl_edit_cfg", 3.0, False)]
+
+
+@pytest.mark.parametrize("tag,lam,cfgpp", H16_CASES)
+def test_ddim_steps_fp16_latent_bit_exact(golden_h16, tag, lam, cfgpp):
+    """fp16 VAE latent -> the whole inversion + regeneration chain is fp16 (every op rounds to fp16)"""
+    g, meta = golden_h16
+    assert meta[tag + "/dtypes"] == ["torch.float16", "torch.float16"]
+    tb = SchedulerTables(10)
+    z, e, z0, zt = T(g[tag + "/unet_z"]), T(g[tag + "/unet_eps"]), T(g[tag + "/z0t"]), T(g[tag + "/zt"])
+    assert z.dtype == torch.float16 and z0.dtype == torch.float16
+    n = z0.shape[0]
+    off = z.shape[0] - n
+    for i, t in enumerate(reversed(tb.timesteps)):          # inversion
+        _, b = O.ddim_step(z[i][0:1], e[i][0:1], e[i][1:2], lam, None, None, cfgpp, False,
+                           sqrt4=tb.ddim_sqrt_coeffs(t, inversion=True))
+        assert b.dtype == torch.float16 and torch.equal(b, z[i + 1][0:1]), f"{tag} inversion step {i}"
+    for i, t in enumerate(tb.timesteps):                    # regeneration
+        a, b = O.ddim_step(z[off + i][0:1], e[off + i][0:1], e[off + i][1:2], lam, None, None, False, cfgpp,
+                           sqrt4=tb.ddim_sqrt_coeffs(t))
+        assert torch.equal(a, z0[i]) and torch.equal(b, zt[i]), f"{tag} step {i}"
+
+
+def test_cuda_scalar_semantics_differs_only_by_scalar_rounding():
+    """"cuda" semantics (the product default) = the same formulas with the scalar-first coefficients left in
+    fp32; it is unpinned (no CUDA torch here), so at least check it is what it claims to be."""
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 4, 8, 8, generator=g)
+    eu, ec = (torch.randn(1, 4, 8, 8, generator=g).half() for _ in range(2))
+    tb = SchedulerTables(50)
+    s4 = tb.ddim_sqrt_coeffs(tb.timesteps[3])
+    a0, b0 = O.ddim_step(z, eu, ec, 0.6, None, None, False, True, sqrt4=s4, semantics="cpu")
+    a1, b1 = O.ddim_step(z, eu, ec, 0.6, None, None, False, True, sqrt4=s4, semantics="cuda")
+    hat = O.cfg_mix(eu, ec, 0.6)
+    c1, c2, c3, c4 = (torch.tensor(float(v)) for v in s4)
+    want_a = (z - (hat.float() * c1).half().float()) / c2
+    want_b = c3 * want_a + (eu.float() * c4).half().float()
+    assert torch.equal(a1, want_a) and torch.equal(b1, want_b)
+    assert not torch.equal(a0, a1) and float((a0 - a1).abs().max()) < 2e-3 * float(a1.abs().max())
+
+
 def test_pinned_sqrt_tables_match_torch_here():
     """The pinned sqrt tables equal torch's own evaluation in the recording container;
     on another host torch.sqrt may differ by 1 ulp (that is why they are pinned)."""

@@ -141,6 +141,88 @@ def test_sd_inversion_trajectory(golden, name, tag, lam):
     assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"]))
 
 
+@pytest.mark.parametrize("name,tag,lam", [("ddim_inversion_cfg++", "G3h/sd_inv_cfgpp", 0.6), ("ddim_inversion", "G3h/sd_inv_cfg", 2.0),
+                                           ("ddim_edit_cfg++", "G3h/sd_edit_cfgpp", 0.6)])
+def test_sd_inversion_trajectory_fp16_latent(golden_h16, name, tag, lam):
+    """the reference's real dtype flow: fp16 VAE latent -> fp16 inversion + regeneration (ddim_step_h kernel path)"""
+    g, meta = golden_h16
+    s, eng = make_sd(name, 10)
+    rec = Rec()
+    z0 = T(g[tag + "/unet_z"])[0][0:1]
+    assert z0.dtype == torch.float16
+    z0_before = z0.clone()
+    s.sample(src_img=None, src_latent=z0, cfg_guidance=lam, prompt=meta[tag]["prompts"], callback_fn=rec, return_latents=True)
+    assert torch.equal(z0, z0_before)              # the caller's latent is not updated in place
+    uz = T(g[tag + "/unet_z"])
+    assert len(eng.calls) == uz.shape[0] == 20
+    for i, c in enumerate(eng.calls):
+        assert c["z_dtype"] == torch.float16 and torch.equal(c["z"], uz[i][0:1]), f"unet call {i}"
+    assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"])) and torch.equal(torch.stack(rec.zt), T(g[tag + "/zt"]))
+
+
+@pytest.mark.parametrize("name,tag,lam", [("ddim_edit_cfg++", "G3h/xl_edit_cfgpp", 0.6), ("ddim_edit", "G3h/xl_edit_cfg", 3.0),
+                                           ("ddim_inversion_cfg++", "G3h/xl_edit_cfgpp_recon", 0.6)])
+def test_sdxl_edit_trajectory_fp16_latent(golden_h16, name, tag, lam):
+    g, meta = golden_h16
+    s, eng = make_xl(name, 10)
+    rec = Rec()
+    p = meta[tag]["prompts"]
+    if name == "ddim_inversion_cfg++":
+        p = p[:2]
+    z0 = T(g[tag + "/unet_z"])[0][0:1]
+    s.sample(prompt1=p, prompt2=p, cfg_guidance=lam, target_size=(64, 64), original_size=(64, 64), callback_fn=rec,
+             src_latent=z0, return_latents=True)
+    uz = T(g[tag + "/unet_z"])
+    assert len(eng.calls) == uz.shape[0]
+    for i, c in enumerate(eng.calls):
+        assert c["z_dtype"] == torch.float16 and torch.equal(c["z"], uz[i][0:1]), f"unet call {i}"
+    assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"]))
+
+
+def test_solver_encode_returns_pipe_dtype_and_latents_are_not_updated_in_place():
+    s, _ = make_sd("ddim_inversion_cfg++", 4)
+    x = torch.rand(1, 3, 64, 64) * 2 - 1
+    assert s.encode(x).dtype == torch.float16          # the reference's fp16 VAE -> fp16 latent
+    z = zT_sd()
+    keep = z.clone()
+    make_sd("ddim_cfg++", 4)[0].sample(cfg_guidance=0.6, prompt=["", "x"], latents=z, return_latents=True)
+    assert torch.equal(z, keep)
+
+
+def test_context_cache_sees_in_place_edits():
+    """the cross-attention context is cached per embedding tensor; an in-place edit must invalidate it"""
+    s, eng = make_sd("ddim_cfg++", 2)
+    uc, c = s.get_text_embed("bad", ["a cat"])
+    z = zT_sd()
+    s.predict_noise(z, 981, uc, c)
+    s.predict_noise(z, 961, uc, c)
+    assert len(eng.contexts) == 1
+    c.mul_(0.5)
+    s.predict_noise(z, 941, uc, c)
+    assert len(eng.contexts) == 2
+
+
+def test_scalar_semantics_defaults():
+    """product (HIP engine) = "cuda" semantics; an injected (test) engine defaults to the golden "cpu" semantics"""
+    s, _ = make_sd("ddim_cfg++", 2)
+    assert s.scalar_semantics == "cpu"
+    eng = MockEngine(scripted_unet)
+    s2 = sd.get_solver("ddim_cfg++", solver_config=cfgn(2), device="cpu", engine=eng, text_encoder=StubSDText(), latent_hw=(8, 8),
+                       vae=StubVAE(0.18215), scalar_semantics="cuda")
+    a = s.sample(cfg_guidance=0.6, prompt=["", "x"], latents=zT_sd(), return_latents=True)[0]
+    b = s2.sample(cfg_guidance=0.6, prompt=["", "x"], latents=zT_sd(), return_latents=True)[0]
+    assert not torch.equal(a, b) and float((a - b).abs().max()) < 5e-3
+    import inspect
+    src = inspect.getsource(sd.StableDiffusion.__init__)
+    assert '"cpu" if kwargs.get("engine") is not None else "cuda"' in src
+
+
+def test_clip_skip_is_not_silently_ignored():
+    x, _ = make_xl("ddim_cfg++", 2)
+    with pytest.raises(NotImplementedError):
+        x.get_text_embed("bad", "a cat", "bad", "a cat", clip_skip=1)
+
+
 @pytest.mark.parametrize("name,tag,nfe,lam", [("dpm++_2m_cfg++", "G4/sd_dpm2m_cfgpp", 20, 0.6), ("dpm++_2m", "G4/sd_dpm2m_cfg", 10, 7.5),
                                               ("euler_cfg++", "G4/sd_euler_cfgpp", 10, 0.6), ("euler", "G4/sd_euler_cfg", 10, 7.5)])
 def test_sd_kdiff_trajectory(golden, name, tag, nfe, lam, monkeypatch):
