@@ -11,10 +11,11 @@ echo "== attention timing"
 for a in "16 8 4096 40" "4 20 1024 64" "4 10 4096 64" "16 8 1024 80" "16 8 4096 40 77" "4 20 1024 64 77"; do timeout 60 python scripts/one_attn.py $a 2>&1 | tail -1 | tee -a $OUT/attn_timing.txt; done
 echo "== attention PMC (SQ)"
 cd /tmp
+rocprofv3 -L > $GRAFT_REPO_ROOT/$OUT/rocprof_counters.txt 2>&1 || true
 for a in "16 8 4096 40" "4 20 1024 64"; do
   tag=$(echo $a | tr ' ' '_')
-  timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS -d $GRAFT_REPO_ROOT/$OUT/pmc_attn_a_$tag -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/scripts/one_attn.py $a 5 > $GRAFT_REPO_ROOT/$OUT/pmc_attn_a_$tag.log 2>&1
-  timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU -d $GRAFT_REPO_ROOT/$OUT/pmc_attn_b_$tag -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/scripts/one_attn.py $a 5 > $GRAFT_REPO_ROOT/$OUT/pmc_attn_b_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $GRAFT_REPO_ROOT/$OUT/pmc_attn_a_$tag -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/scripts/one_attn.py $a 5 > $GRAFT_REPO_ROOT/$OUT/pmc_attn_a_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $GRAFT_REPO_ROOT/$OUT/pmc_attn_b_$tag -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/scripts/one_attn.py $a 5 > $GRAFT_REPO_ROOT/$OUT/pmc_attn_b_$tag.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python scripts/pmc_sq.py $OUT/pmc_attn_a_* $OUT/pmc_attn_b_* > $OUT/pmc_attn_summary.txt 2>&1; grep -A12 "attn_kernel" $OUT/pmc_attn_summary.txt | head -60
