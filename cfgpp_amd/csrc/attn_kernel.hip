@@ -3,8 +3,11 @@
 //   O[b, q, h*d + :] = softmax(Q K^T * scale) V      Q,K: [B*heads][tok_pad][dp]   V^T: [B*heads][dp][tok_pad]
 //
 // Layout contract (written by the QKV GEMM epilogue, EPI_HEADS): head-major, head
-// dim zero-padded to dp = round_up(d, 32), V stored TRANSPOSED so that every MFMA
-// operand is a contiguous 8/16-byte LDS read and no cross-lane shuffles are needed:
+// dim zero-padded to dp = round_up(d, 32), V stored TRANSPOSED with the keys of every
+// 32-key block PERMUTED (bits 2 and 3 of the key index swapped: cfgpp_vt_pos in common.h) so
+// that every MFMA operand is ONE contiguous 16-byte LDS read and no cross-lane shuffles are needed
+// (the 8 k-slots a lane feeds to a PV MFMA are its accumulator registers 8*tt .. 8*tt+7 = keys
+// 16*tt + 8*b + 4*hi + r, which the permutation makes consecutive):
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_f16 (A = K rows = keys, B = Q^T cols =
 //     queries): each lane ends up holding 16 scores of ONE query per 32-key tile.
 //   * Online softmax entirely in registers (one __shfl_xor(…,32) for the row max); Q is pre-scaled by
@@ -19,9 +22,16 @@
 //     denominator sums exactly the fp16 P values the numerator uses).
 //   * O^T += V^T P^T: the B operand (P^T) is exactly the lane's own 8 consecutive
 //     accumulator registers converted to fp16 (the MFMA k-slot <-> key assignment is
-//     free as long as A and B agree), the A operand is 2 x ds_read_b64 from V^T.
-//   * 4 waves x 32 queries per workgroup, 64-key tiles, double-buffered LDS + register
-//     prefetch two tiles ahead (one barrier per tile), padded LDS rows (conflict-free ds_read_b128).
+//     free as long as A and B agree), the A operand is one ds_read_b128 from the permuted V^T.
+//   * 4 waves x 32 queries per workgroup, 64-key tiles.
+//   * dp = 64 (d = 40: SD1.5 64x64 level, d = 64: every SDXL level - > 90 % of the attention time):
+//     attn64_kernel.  K and V^T tiles are both [64 rows][128 B]; they go HBM -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4: no VGPR staging, no ds_write pass - the VGPR -> LDS store path was what
+//     saturated the CU's LDS pipe: PMC showed 33 % of the LDS cycles as bank conflicts of the old 2 x
+//     ds_read_b64 V reads and 47 % of the wave time parked) into unpadded rows with the igemm's XOR swizzle
+//     applied to the per-lane SOURCE chunk, on a 3-stage ring: a tile has two tile times to land, one
+//     raw s_barrier per tile, counted vmcnt.
+//   * other head dims (80, 160): attn_kernel, register-staged double buffering, padded LDS rows.
 // Cross-attention (77 keys padded to 128) uses the same kernel with nk_valid = 77.
 // softmax statistics and accumulation are fp32; P is rounded to fp16 for the PV
 // product (same as the reference's SDPA flash path under fp16 autocast).
@@ -193,16 +203,11 @@ attn_kernel(const AttnArgs a) {
                 for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[qt][j] = (half_t)s[qt][kt][8 * tt + j];
-                // k-slot j = b*4 + r  <->  key = kt*32 + 8*(2*tt + b) + 4*hi + r
-                const int kcol0 = kt * 32 + 16 * tt + 4 * hi;
+                // k-slot j = b*4 + r  <->  key = kt*32 + 8*(2*tt + b) + 4*hi + r  <->  V^T column kt*32 + 16*tt + 8*hi + j
+                const int kpos0 = kt * 32 + 16 * tt + 8 * hi;
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const char* vrow = Vs + (i * 32 + l31) * VPITCH;
-                    const half4_t v0 = *reinterpret_cast<const half4_t*>(vrow + (kcol0) * 2);
-                    const half4_t v1 = *reinterpret_cast<const half4_t*>(vrow + (kcol0 + 8) * 2);
-                    half8_t vf;
-                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                    const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + (i * 32 + l31) * VPITCH + kpos0 * 2);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         oacc[qt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qt], oacc[qt][i], 0, 0, 0);
@@ -249,6 +254,207 @@ attn_kernel(const AttnArgs a) {
     }
 }
 
+// ---- dp = 64 ------------------------------------------------------------------------------------
+// K tile  : LDS [64 keys  ][64 halfs], row = key,   16-B chunk c = 8 head dims
+// V^T tile: LDS [64 d-rows][64 keys ], row = d,     16-B chunk c = 8 (permuted) keys
+// physical chunk = logical chunk ^ ((row >> 1) & 7); one DMA piece = 8 rows x 128 B = 64 lanes x 16 B.
+template <int D16, bool ONES, int NST>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU; 2: 32 KB, 4 / CU)
+__global__ void __launch_bounds__(256)
+attn64_kernel(const AttnArgs a) {
+    constexpr int DP = 64, DT = 2;
+    constexpr int TILE = 64 * 128;               // bytes of one K or V^T tile
+    constexpr int STAGE = 2 * TILE;
+    constexpr int PPW = 4;                       // DMA pieces per wave per tile: 8 (K) + 8 (V^T) over 4 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
+    const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
+    const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
+
+    // DMA source addressing: lane -> (row r8 = lane >> 3 of the piece, physical chunk pc = lane & 7); the wave's
+    // pieces are K rows [16 * wid, 16 * wid + 16) and V^T rows [16 * wid, 16 * wid + 16) of the tile
+    const int r8 = lane >> 3, pc = lane & 7;
+    const half_t* ksrc[2]; const half_t* vsrc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = wid * 16 + h * 8 + r8;
+        const int lc = pc ^ ((row >> 1) & 7);
+        ksrc[h] = Kb + (long)row * DP + lc * 8;                    // + t * 64 * DP per tile
+        vsrc[h] = Vb + (long)row * a.k_tok_pad + lc * 8;           // + t * 64 per tile
+    }
+    auto dma_tile = [&](int t, int stage) {
+        char* Ks = smem + stage * STAGE;
+        char* Vs = Ks + TILE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[h] + (long)t * 64 * DP),
+                                             (__attribute__((address_space(3))) void*)(Ks + (wid * 16 + h * 8) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[h] + (long)t * 64),
+                                             (__attribute__((address_space(3))) void*)(Vs + (wid * 16 + h * 8) * 128), 16, 0, 0);
+        }
+    };
+
+    const int ntiles = (a.nk_valid + 63) >> 6;
+    const int tail = a.nk_valid & 63;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) if (t < ntiles) dma_tile(t, t);
+
+    // Q^T fragments (B operand), pre-multiplied by d^-1/2 * log2(e); ordinary loads, issued after the first DMAs
+    half8_t qf[D16];
+#pragma unroll
+    for (int ks = 0; ks < D16; ++ks) {
+        const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
+    }
+
+    f32x16 oacc[DT];
+    f32x16 negm;
+    float l_run = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+
+    const int fsw = (l31 >> 1) & 7;
+    const int frow = l31 * 128;
+    for (int t = 0; t < ntiles; ++t) {
+        // tile t landed once at most the NST-2 younger tiles' pieces are outstanding; the barrier makes every wave's pieces
+        // visible and tells that everyone is done reading tile t-1, whose stage tile t+NST-1 is about to overwrite
+        if (NST > 2 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NST - 1 < ntiles) dma_tile(t + NST - 1, (t + NST - 1) % NST);
+        const char* Ks = smem + (t % NST) * STAGE;
+        const char* Vs = Ks + TILE;
+
+        // ---- S^T - m = K Q^T + (-m) for two 32-key sub-tiles (log2 domain) ----
+        f32x16 s[2];
+        {
+            half8_t kf[2][D16];                  // all K fragments of the tile in flight before the first MFMA
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < D16; ++ks)
+                    kf[kt][ks] = *reinterpret_cast<const half8_t*>(Ks + kt * 32 * 128 + frow + ((((ks << 1) | hi) ^ fsw) << 4));
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler would re-serialise them)
+#pragma unroll
+            for (int ks = 0; ks < D16; ++ks)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? negm : s[kt], 0, 0, 0);
+        }
+        if (tail != 0 && t == ntiles - 1) {      // wave-uniform: mask keys >= nk_valid (cross-attention, 77 keys)
+            const int kbase = t * 64 + 4 * hi;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + kt * 32 + (r & 3) + 8 * (r >> 2);
+                    s[kt][r] = key < a.nk_valid ? s[kt][r] : -INFINITY;
+                }
+        }
+        // ---- online softmax: per query = per lane column; keys across 32 registers and the two half-waves ----
+        float mx = s[0][0];                      // tile max RELATIVE to m_ref
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (t == 0 || !__all(mx <= 0.f)) {       // some query's max grew (always on the first tile): re-reference (exact)
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] -= delta;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][r]);
+                s[kt][r] = pv;
+                if constexpr (!ONES) psum += pv;
+            }
+        if constexpr (!ONES) l_run += psum;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                half8_t pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (half_t)s[kt][8 * tt + j];
+                const int lc = kt * 4 + 2 * tt + hi;               // logical 16-B chunk of the (permuted) key axis
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + i * 32 * 128 + frow + ((lc ^ fsw) << 4));
+                    oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- finalize: O = O^T / l, store token-major ----
+    float l_tot;
+    if constexpr (ONES) {
+        const int dr = a.d & 31;
+        float lv = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) if (dr == 8 * g) lv = oacc[DT - 1][4 * g];
+        l_tot = __shfl(lv, l31);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv_l = 1.0f / l_tot;
+    const int q = q0 + l31;
+    if (q < a.nq) {
+        const int b = bh / a.heads, head = bh - b * a.heads;
+        half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = i * 32 + 8 * g + 4 * hi;
+                if (dd < a.d) {
+                    half4_t o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[i][4 * g + k] * inv_l);
+                    *reinterpret_cast<half4_t*>(orow + dd) = o;
+                }
+            }
+    }
+}
+
+template <int D16, bool ONES, int NST>
+int launch_attn64(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int smem = NST * 2 * 64 * 128;
+    static bool attr_set = false;
+    auto kern = attn64_kernel<D16, ONES, NST>;
+    if (!attr_set) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+    return 0;
+}
+
 // sets row d of every V^T matrix to 1.0 (see the kernel header); vt [BH][dp][tok_pad]
 __global__ void attn_ones_row_kernel(half_t* vt, int BH, int d, int dp, int tok_pad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,7 +479,11 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel on a 3-stage ring, 2 = 2-stage ring, 0 = register-staged kernel (A/B switch)
+
 extern "C" {
+
+void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode; }
 
 // V^T contract: when d is not a multiple of 32, row d of every [dp][tok_pad] matrix must hold ones (softmax
 // denominator through the PV MFMA).  Call once after allocating / zeroing the buffer; the QKV epilogue never
@@ -305,6 +515,19 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     hipStream_t s = (hipStream_t)stream;
     const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
     const bool ones = (d % 32) != 0;
+    if (dt == 2 && g_attn_dma) {                   // dp = 64 (d = 40, 48, 56, 64): LDS-DMA kernel
+        int rc;
+        if (g_attn_dma == 2) {
+            if (d16 == 3) rc = launch_attn64<3, true, 2>(a, grid, s);
+            else rc = ones ? launch_attn64<4, true, 2>(a, grid, s) : launch_attn64<4, false, 2>(a, grid, s);
+        } else {
+            if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
+            else rc = ones ? launch_attn64<4, true, 3>(a, grid, s) : launch_attn64<4, false, 3>(a, grid, s);
+        }
+        if (rc) return -1;
+        CFGPP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define ATTN_CASE(D16_, DT_) \
     if (d16 == D16_ && dt == DT_) { if (ones ? launch_attn<D16_, DT_, true, 1>(a, grid, s) : launch_attn<D16_, DT_, false, 1>(a, grid, s)) return -1; } else
     ATTN_CASE(1, 1) ATTN_CASE(2, 1) ATTN_CASE(3, 2) ATTN_CASE(4, 2) ATTN_CASE(5, 3) ATTN_CASE(6, 3)

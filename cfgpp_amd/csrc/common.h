@@ -50,6 +50,12 @@ struct RowMap {
     int ld;       // elements per row / pixel
 };
 
+// Column of key `tok` in a V^T matrix (attention contract, attn_kernel.hip): within every 32-key block bits 2 and 3
+// of the key index are swapped, which makes the 8 keys a lane feeds to one PV MFMA contiguous.
+__host__ __device__ __forceinline__ int cfgpp_vt_pos(int tok) {
+    return (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact-GELU x*Phi(x) with erfc by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16
 // output resolution): 1 rcp + 1 exp2 + a degree-5 Horner instead of libm erff (~3x fewer VALU ops in the

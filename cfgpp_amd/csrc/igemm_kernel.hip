@@ -128,7 +128,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                     }
                     const long bh = (long)b * p.heads + head;
                     if (part == 2) {
-                        half_t* dst = p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok;
+                        half_t* dst = p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + cfgpp_vt_pos(tok);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) dst[(long)k * p.tok_pad] = (half_t)v[k];
                     } else {
@@ -262,26 +262,15 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 // AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
-// KG > 1 (DMA path only): the workgroup carries KG wave GROUPS of WM x WN waves; every group owns the whole
-// BM x BN output tile but only 4 / KG of the four 16-deep k-steps of each 64-deep K-tile.  The groups' fp32
-// accumulators are summed through LDS after the K loop (fixed order: group 0 + group 1).  Twice the waves
-// on a grid whose tile count cannot fill the CUs with two workgroups each (e.g. M = 4096, N = 1280:
-// 256 tiles of 128 x 160), at the price of a different - still deterministic - summation order, so this
-// variant is chosen by a shape rule only, never by the timing-based tuner.
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int KG = 1>
-__global__ void __launch_bounds__(64 * WM * WN * KG)
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
+__global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
-    constexpr int NTHR = 64 * WM * WN * KG;
-    static_assert(KG == 1 || (GLDS && (KG == 2 || KG == 4)), "k-groups need the DMA path");
+    constexpr int NTHR = 64 * WM * WN;
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
-    constexpr int A_CH = (BM + RSTEP - 1) / RSTEP, B_CH = (BN + RSTEP - 1) / RSTEP;
-    // a tile side that is not a multiple of the loader pass (160 rows, 64 per pass) ends with a partial pass that
-    // only the first waves take part in (wave-uniform guard); DMA path with a 2-stage ring only (vmcnt(0) waits)
-    constexpr bool A_PART = BM % RSTEP != 0, B_PART = BN % RSTEP != 0;
-    static_assert((!A_PART && !B_PART) || (GLDS && NST == 2), "partial loader pass needs the 2-stage DMA path");
-    static_assert(RSTEP % 8 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile/loader mismatch");
+    constexpr int A_CH = BM / RSTEP, B_CH = BN / RSTEP;
+    static_assert(BM % RSTEP == 0 && BN % RSTEP == 0, "tile/loader mismatch");
     constexpr int STAGE_BYTES = (BM + BN) * 128;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -311,9 +300,7 @@ igemm_kernel(const IGemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(wid / (WM * WN));     // k-group of this wave
-    const int wq = wid - kg * (WM * WN);
-    const int wm = wq / WN, wn = wq - wm * WN;
+    const int wm = wid / WN, wn = wid - wm * WN;
 
     // ---- loader state ----
     const int lrow = tid >> 3, lchunk = tid & 7;
@@ -409,14 +396,12 @@ igemm_kernel(const IGemmArgs p) {
                 pix = a_pix[j] + dpix;
             }
             const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
-            if (!A_PART || wave_row0 + j * RSTEP < BM)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(As + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_CH; ++j) {
             const half_t* g = b_ptr[j] + ((long)kt << 6);
-            if (!B_PART || wave_row0 + j * RSTEP < BN)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(Bs + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
         }
@@ -452,9 +437,8 @@ igemm_kernel(const IGemmArgs p) {
         // cost ~60 cycles each and the partner wave's MFMAs cover them; the second half of the tile is the
         // landing time before the end-of-tile vmcnt(0) + barrier.
         constexpr int NP = A_CH + B_CH;               // DMA pieces per wave per K-tile
-        constexpr int KS = 4 / KG;                    // k-steps of a K-tile this wave computes
-        constexpr int NM = KS * MT * NT;              // MFMAs per wave per K-tile
-        constexpr bool ILV = (WM * WN * KG >= 8);     // 4-wave tiles overlap through co-resident blocks instead
+        constexpr int NM = 4 * MT * NT;               // MFMAs per wave per K-tile
+        constexpr bool ILV = (WM * WN >= 8);          // 4-wave tiles overlap through co-resident blocks instead
         constexpr int SPAN = ILV ? (NM * 5) / 8 : 0;  // pieces go out during the first 5/8 of the MFMAs
         // NST-stage LDS ring: tile kt is computed from stage (kt - kt_begin) % NST while tiles kt+1 .. kt+NST-1
         // are in flight / landed; a tile has NST-1 tile times to arrive (memory latency under load is of the
@@ -470,7 +454,6 @@ igemm_kernel(const IGemmArgs p) {
             const int cur = (kt - kt_begin) % NST;
             const char* As = smem + cur * STAGE_BYTES;
             const char* Bs = As + BM * 128;
-            const int ks0 = kg * KS;                   // first k-step of this wave's k-group
             // per-tile scalars of the NEXT tile's gather
             const half_t* src = p.a0; int cs = 0, Cs = p.C0, dpix = 0, dy = 0, dx = 0;
             char* Asn = smem + ((kt - kt_begin + NST - 1) % NST) * STAGE_BYTES;
@@ -498,14 +481,12 @@ igemm_kernel(const IGemmArgs p) {
                         pix = a_pix[j] + dpix;
                     }
                     const half_t* g = src + (long)pix * Cs + cs + schunk * 8;
-                    if (!A_PART || wave_row0 + j * RSTEP < BM)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(Asn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
                 } else {
                     const int j = q - A_CH;
                     const half_t* g = b_ptr[j] + ((long)(kt + NST - 1) << 6);
-                    if (!B_PART || wave_row0 + j * RSTEP < BN)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(Bsn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
                 }
             };
@@ -529,16 +510,16 @@ igemm_kernel(const IGemmArgs p) {
                 // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
                 half8_t xa[2][MT], wb[2][NT];
                 {
-                    const int coff = (((ks0 << 1) | fhi) ^ fsw) << 4;
+                    const int coff = ((0 | fhi) ^ fsw) << 4;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 32 * 128 + coff);
                 }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (ks < KS - 1) {
-                        const int coff = ((((ks0 + ks + 1) << 1) | fhi) ^ fsw) << 4;
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < 3) {
+                        const int coff = ((((ks + 1) << 1) | fhi) ^ fsw) << 4;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) xa[(ks + 1) & 1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
 #pragma unroll
@@ -556,8 +537,8 @@ igemm_kernel(const IGemmArgs p) {
                 // 10 accumulator tiles per wave (256x320): no room for a second fragment set; 10 MFMAs per k-step
                 // (320 cycles) give the partner wave on the SIMD time to cover the LDS latency instead
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int coff = ((((ks0 + ks) << 1) | fhi) ^ fsw) << 4;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
                     half8_t xa[MT], wb[NT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 32 * 128 + coff);
@@ -648,36 +629,6 @@ igemm_kernel(const IGemmArgs p) {
     }
 
     const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
-    if constexpr (KG > 1) {
-        // k-group reduction through LDS in register order (lane-contiguous: conflict-free).  The K loop ended
-        // with a barrier, so the tile stages are free.  Fixed order: acc(group 0) + group 1 (+ group 2 + group 3).
-        constexpr int REGS = MT * NT * 16;
-        float* red = reinterpret_cast<float*>(smem);
-        if (kg > 0) {
-            float* dst = red + (long)((kg - 1) * (WM * WN) + wq) * REGS * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[((i * NT + j) * 16 + r) * 64] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int g = 1; g < KG; ++g) {
-                const float* src = red + (long)((g - 1) * (WM * WN) + wq) * REGS * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * NT + j) * 16 + r) * 64];
-            }
-        }
-        __syncthreads();            // every group-0 wave has its sums before the staged epilogue reuses the LDS
-        if (kg > 0) return;
-    }
     if (is_tail) {
         // fp32 partial, register order, coalesced: ws[((block * REGS + r) * NTHR) + tid]
         float* ws = p.ws + (long)(bid - p.n_main) * (MT * NT * 16) * NTHR + tid;
@@ -691,12 +642,12 @@ igemm_kernel(const IGemmArgs p) {
     }
     if (p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
-        igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wq * (32 * (WTN * 2 + 16)));
+        igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)));
         return;
     }
     if constexpr (NT % 2 == 0) {
         if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
-            igemm_epilogue_geglu_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wq * (32 * ((NT / 2) * 64 + 16)));
+            igemm_epilogue_geglu_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)));
             return;
         }
     }
@@ -748,16 +699,14 @@ static int g_big_tiles = 1;
 extern "C" void cfgpp_igemm_set_big_tiles(int on) { g_big_tiles = on ? 1 : 0; }
 static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int KG = 1>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
-    constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN * KG;
-    constexpr int stage_bytes = NST * (BM + BN) * 128;
-    constexpr int red_bytes = (KG - 1) * WM * WN * (WTM / 32) * (WTN / 32) * 16 * 64 * 4;     // k-group partials
-    constexpr int smem = stage_bytes > red_bytes ? stage_bytes : red_bytes;
+    constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
+    constexpr int smem = NST * (BM + BN) * 128;
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST, KG>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -770,7 +719,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
     // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
     // finishes them.  S is chosen so that T*S fills the resident slots once or twice.
-    if (KG == 1 && g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
+    if (g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
         int S = (slots + T - 1) / T;                       // one full round
         if (KT / S < 12) S = KT / 12;
         if (S > 16) S = 16;
@@ -787,13 +736,13 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2, int KG = 1>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST, KG>(a, stream);
-        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST, KG>(a, stream);
-        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST, KG>(a, stream);
-        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST, KG>(a, stream);
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
+        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST>(a, stream);
+        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST>(a, stream);
+        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST>(a, stream);
         default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
     }
 }
@@ -823,7 +772,7 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // at M = 4096, N = 1280 and 128 x 320 at M = 16384, N = 640)
         case 7: return launch_cfg<4, 1, 32, 160, true>(a, stream);     // 128 x 160, 4 waves, 2 workgroups / CU
         case 8: return launch_cfg<4, 2, 32, 160, true>(a, stream);     // 128 x 320, 8 waves
-        case 9: return launch_cfg<4, 1, 32, 160, true, 2, 2>(a, stream);   // 128 x 160, 2 k-groups x 4 waves (rule-chosen only)
+        case 9: return launch_cfg<4, 1, 32, 160, true, 3>(a, stream);  // 128 x 160, 4 waves, 3-stage ring, ONE workgroup / CU (256-tile grids)
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -876,7 +825,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || ((h == 5 || h == 7 || h == 8) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const bool valid = (h == 1 || h == 4 || h == 6 || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     return launch_config(cfg, a, stream);

@@ -7,9 +7,19 @@
 // value is rounded to fp16 once - exactly the value the following fp16 conv /
 // linear consumes in the reference.
 //
-// Three launches, all deterministic (no atomics, fixed summation order -> bit-identical runs):
-// (1) per-block partial sums with coalesced 16-B reads, (2) a tiny fixed-order finalize to
-// mean / rstd, (3) apply.  Algorithmic bytes per element: 2 (stats read) + 2 (apply read) + 2 (write).
+// Two forms, both deterministic (no atomics, fixed summation order -> bit-identical runs) and both
+// free of the E[x^2] - mean^2 cancellation (activations with |mean| >> sigma, e.g. what the fp16-fix
+// VAE exists for):
+//  (1) SLAB kernel, ONE launch, 4 B / element (one read, one write): a workgroup owns all H*W pixels
+//      of one sample for a set of gs consecutive groups (gs*C/G channels = 80 ... 240 B per pixel) and
+//      holds that slab in REGISTERS (the 512 KB register file of a CU is its largest memory); mean and
+//      variance are the exact two-pass form (sum, then sum of squared deviations), like torch.
+//      Used whenever the slab fits 16 x 16-B chunks per thread of a <= 960-thread workgroup (H*W <= 1024 at
+//      every channel count of the two UNets): all 32x32 / 16x16 / 8x8 GroupNorms of SD1.5 and the 32x32 ones of SDXL.
+//  (2) two launches for larger slabs (64x64 and 128x128 levels): per-block partial sums of (x - pivot),
+//      (x - pivot)^2 with a per-(sample, group) pivot = the group's first element, then an apply kernel
+//      whose prologue reduces the partials in a fixed order.  6 B / element.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -20,8 +30,8 @@ struct GNArgs {
     half_t* dst;
     const float* gamma;   // [C]
     const float* beta;    // [C]
-    float* stats;         // [N][nblk][G][2] fp32 per-block partial (sum, sumsq)
-    const float* mean_rstd;   // [N][G][2] written by gn_finalize_kernel
+    float* stats;         // [N][nblk][G][2] fp32 per-block partial (sum, sumsq) of (x - pivot)
+    int nblk;
     int N, H, W;
     int C0, C1;           // channels of src0 / src1 (C = C0 + C1), both multiples of 8
     int G;                // groups
@@ -29,15 +39,153 @@ struct GNArgs {
     int silu;
     int pix_per_block;
     int dst_padded;       // 1: dst is halo-padded NHWC, 0: dst is token-major [N*H*W][C]
+    int gs;               // slab kernel: groups per workgroup
 };
 
 __device__ __forceinline__ long pad_off(int n, int y, int x, int H, int W) {
     return ((long)(n * (H + 2) + y + 1) * (W + 2) + x + 1);
 }
 
-// Pass 1: per-(sample, pixel-block) partial sums of every group, DETERMINISTIC (no atomics): each thread
-// sums 8 channels over its pixels, the block combines them through LDS in a fixed order and writes
-// part[n][blk][g][2].  Pass 2 (gn_finalize_kernel) reduces the blocks in a fixed order to mean / rstd.
+// pivot of (sample n, group g): the group's first channel at the sample's first pixel (any value within a few
+// sigma of the group mean removes the cancellation; this one costs one L2 hit)
+__device__ __forceinline__ float gn_pivot(const GNArgs& a, int n, int c_first) {
+    const long p = pad_off(n, 0, 0, a.H, a.W);
+    return c_first < a.C0 ? (float)a.src0[p * a.C0 + c_first] : (float)a.src1[p * a.C1 + (c_first - a.C0)];
+}
+
+// Makes the packed fp16 slab registers opaque between the passes: otherwise the compiler converts every element
+// to fp32 once and keeps all of them live (2x the registers; spills at 16+ chunks per thread).
+__device__ __forceinline__ void gn_opaque(half8_t& v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 u = __builtin_bit_cast(u32x4, v);
+    asm volatile("" : "+v"(u));
+    v = __builtin_bit_cast(half8_t, u);
+}
+
+// ---- (1) slab kernel ------------------------------------------------------------------------------
+// grid.x = N * (G / gs) workgroups (XCD-contiguous order: neighbouring channel ranges of one sample share an
+// L2, so the 128-B lines their 80..240-B segments straddle are fetched from HBM once).  NT = cpp * R threads,
+// cpp = 16-B chunks per pixel segment: thread t owns chunk column cc = t % cpp (its 8 channels, hence its
+// group(s), scale and shift are loop-invariant) of pixels t / cpp + j * R.
+template <int MAXCH, int NT>
+__global__ void __launch_bounds__(NT)
+gn_slab_kernel(GNArgs a) {
+    __shared__ float s_part[2][NT];          // per-thread partials (lower / upper group of the thread's chunk)
+    __shared__ float s_col[2][32];           // per chunk-column totals
+    __shared__ float s_grp[4];               // per local group: mean, then rstd
+    const int C = a.C0 + a.C1, cpg = C / a.G;
+    const int chw = a.gs * cpg, cpp = chw >> 3;
+    const int S = a.G / a.gs;
+    const int HW = a.H * a.W;
+    // XCD-contiguous remap of the workgroup index (bijective form)
+    const int T = gridDim.x, bid = blockIdx.x;
+    const int q = T >> 3, r8 = T & 7, xcd = bid & 7, idx = bid >> 3;
+    const int w = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int n = w / S, sset = w - n * S;
+    const int tid = threadIdx.x;
+    const int R = NT / cpp;                  // pixel rows per pass (NT is a multiple of cpp by construction)
+    const int prow = tid / cpp, cc = tid - prow * cpp;
+    const int c = sset * chw + cc * 8;       // first channel of this thread's chunk (global channel index)
+    const half_t* src; int cs, Cs;
+    if (c < a.C0) { src = a.src0; cs = c; Cs = a.C0; } else { src = a.src1; cs = c - a.C0; Cs = a.C1; }
+    // local groups of the chunk: channels [cc*8, cc*8+8) of the workgroup's range; at most two (cpg >= 8)
+    const int g_lo = (cc * 8) / cpg;
+    const int split = min(8, (g_lo + 1) * cpg - cc * 8);       // elements [0, split) belong to g_lo, the rest to g_lo + 1
+    const float invW = 1.0f / (float)a.W;
+    const long pbase = (long)n * (a.H + 2) * (a.W + 2) + (a.W + 2) + 1;
+    auto poff = [&](int p) -> long { return pbase + p + 2 * (int)(((float)p + 0.5f) * invW); };
+
+    half8_t v[MAXCH];
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int p = prow + j * R;
+        if (p < HW) v[j] = *reinterpret_cast<const half8_t*>(src + poff(p) * Cs + cs);
+        else { for (int k = 0; k < 8; ++k) v[j][k] = (half_t)0.f; }
+    }
+    // fixed-order block reduction of (lo, hi) per-thread partials into per-group totals:
+    // s_part -> one wave per chunk column (shuffle tree over the R rows) -> s_col -> thread g sums its columns
+    const int lane = tid & 63, wid = tid >> 6, nw = NT >> 6;
+    auto block_reduce = [&](float lo, float hi, float* out4 /* s_grp */) {
+        s_part[0][cc * R + prow] = lo; s_part[1][cc * R + prow] = hi;
+        __syncthreads();
+        for (int col = wid; col < cpp; col += nw) {
+            float x = 0.f, y = 0.f;
+            for (int rr = lane; rr < R; rr += 64) { x += s_part[0][col * R + rr]; y += s_part[1][col * R + rr]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+            if (lane == 0) { s_col[0][col] = x; s_col[1][col] = y; }
+        }
+        __syncthreads();
+        if (tid < a.gs) {
+            float t = 0.f;
+            for (int col = 0; col < cpp; ++col) {
+                const int gl = (col * 8) / cpg;
+                if (gl == tid) t += s_col[0][col];
+                if (gl + 1 == tid) t += s_col[1][col];
+            }
+            out4[tid] = t;
+        }
+        __syncthreads();
+    };
+    const float inv_cnt = 1.0f / ((float)cpg * (float)HW);
+    // pass 1: mean
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float f = (float)v[j][k]; if (k < split) lo += f; else hi += f; }
+    block_reduce(lo, hi, s_grp);
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) gn_opaque(v[j]);
+    const float mean_lo = s_grp[g_lo] * inv_cnt;
+    const float mean_hi = (split < 8) ? s_grp[g_lo + 1] * inv_cnt : 0.f;
+    __syncthreads();                         // s_grp is rewritten by pass 2
+    // pass 2: sum of squared deviations (padding chunks beyond HW hold zeros: exclude them)
+    lo = 0.f; hi = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        if (prow + j * R < HW) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float f = (float)v[j][k];
+                if (k < split) { const float d = f - mean_lo; lo += d * d; } else { const float d = f - mean_hi; hi += d * d; }
+            }
+        }
+    }
+    block_reduce(lo, hi, s_grp);
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) gn_opaque(v[j]);
+    const float rstd_lo = rsqrtf(s_grp[g_lo] * inv_cnt + a.eps);
+    const float rstd_hi = (split < 8) ? rsqrtf(s_grp[g_lo + 1] * inv_cnt + a.eps) : 0.f;
+    // apply
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float m = k < split ? mean_lo : mean_hi, rs = k < split ? rstd_lo : rstd_hi;
+        const float ga = a.gamma[c + k] * rs;
+        sc[k] = ga; sh[k] = a.beta[c + k] - m * ga;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        int p = prow + j * R;
+        asm volatile("" : "+v"(p));          // recompute the pixel offset here instead of keeping MAXCH 64-bit addresses live
+        if (p < HW) {
+            half8_t o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float f = (float)v[j][k] * sc[k] + sh[k];
+                if (a.silu) f = silu_f(f);
+                o[k] = (half_t)f;
+            }
+            const long orow = a.dst_padded ? poff(p) : ((long)n * HW + p);
+            *reinterpret_cast<half8_t*>(a.dst + orow * C + c) = o;
+        }
+    }
+}
+
+// ---- (2) two-launch form ---------------------------------------------------------------------------
+// Pass 1: per-(sample, pixel-block) partial sums of (x - pivot), (x - pivot)^2 for every group: each thread sums
+// 8 channels over its pixels, the block combines them through LDS in a fixed order and writes part[n][blk][g][2].
 __global__ void __launch_bounds__(256)
 gn_stats_kernel(GNArgs a) {
     __shared__ float s_part[256][16];   // [thread][8 sums | 8 sums of squares]
@@ -67,6 +215,9 @@ gn_stats_kernel(GNArgs a) {
             const int c = chunk * 8;
             const half_t* src; int cs, Cs;
             if (c < a.C0) { src = a.src0; cs = c; Cs = a.C0; } else { src = a.src1; cs = c - a.C0; Cs = a.C1; }
+            float pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pv[k] = gn_pivot(a, n, ((c + k) / cpg) * cpg);
             // 4 independent 16-B loads in flight per thread; the per-thread summation order is unchanged
             int p = p0 + psub;
             for (; p + 3 * ppi < p1; p += 4 * ppi) {
@@ -76,12 +227,12 @@ gn_stats_kernel(GNArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { float f = (float)v[u][k]; s[k] += f; q[k] += f * f; }
+                    for (int k = 0; k < 8; ++k) { const float f = (float)v[u][k] - pv[k]; s[k] += f; q[k] += f * f; }
             }
             for (; p < p1; p += ppi) {
                 const half8_t v = *reinterpret_cast<const half8_t*>(src + poff(p) * Cs + cs);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { float f = (float)v[k]; s[k] += f; q[k] += f * f; }
+                for (int k = 0; k < 8; ++k) { const float f = (float)v[k] - pv[k]; s[k] += f; q[k] += f * f; }
             }
         }
 #pragma unroll
@@ -110,26 +261,8 @@ gn_stats_kernel(GNArgs a) {
     }
 }
 
-// Pass 2: fixed-order reduction over the nblk pixel-blocks -> (mean, rstd) per (sample, group).
-// One 64-lane wave per (n, g): lane l sums blocks l, l+64, ... in order, then a fixed xor-shuffle tree.
-__global__ void __launch_bounds__(64)
-gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mr, int nblk, int G, float inv_cnt, float eps) {
-    const int n = blockIdx.x / G, g = blockIdx.x - n * G;
-    float s = 0.f, q = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 64) {
-        const float* p = part + (((long)n * nblk + b) * G + g) * 2;
-        s += p[0]; q += p[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-    if (threadIdx.x == 0) {
-        const float mean = s * inv_cnt;
-        float var = q * inv_cnt - mean * mean;
-        var = var < 0.f ? 0.f : var;
-        mr[((long)n * G + g) * 2] = mean; mr[((long)n * G + g) * 2 + 1] = rsqrtf(var + eps);
-    }
-}
-
+// Pass 2: apply.  Prologue: the fixed-order reduction of the nblk (<= 256) stats blocks to (mean, rstd) per group,
+// one wave per 8 groups (lane l reads block l, xor-shuffle tree), recomputed by every workgroup (16 KB of L2 reads).
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(GNArgs a) {
     __shared__ float s_mean[64], s_rstd[64];
@@ -140,8 +273,24 @@ gn_apply_kernel(GNArgs a) {
     const int HW = a.H * a.W;
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
-    for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
-        s_mean[g] = a.mean_rstd[((long)n * a.G + g) * 2]; s_rstd[g] = a.mean_rstd[((long)n * a.G + g) * 2 + 1];
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const float inv_cnt = 1.0f / ((float)cpg * (float)HW);
+        for (int g = wid; g < a.G; g += 4) {
+            float s = 0.f, q = 0.f;
+            for (int b = lane; b < a.nblk; b += 64) {
+                const float* p = a.stats + (((long)n * a.nblk + b) * a.G + g) * 2;
+                s += p[0]; q += p[1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+            if (lane == 0) {
+                const float dm = s * inv_cnt;                      // mean - pivot
+                float var = q * inv_cnt - dm * dm;                 // benign: |dm| is a few sigma at most
+                var = var < 0.f ? 0.f : var;
+                s_mean[g] = gn_pivot(a, n, g * cpg) + dm; s_rstd[g] = rsqrtf(var + a.eps);
+            }
+        }
     }
     __syncthreads();
     const int ppi = max(1, (int)blockDim.x / chunks);
@@ -192,6 +341,13 @@ gn_apply_kernel(GNArgs a) {
         }
         if (chunks <= (int)blockDim.x) break;
     }
+}
+
+int g_gn_mode = 0;        // 0 = auto, 1 = always the two-launch form, 2 = slab kernel whenever the slab fits
+
+template <int MAXCH, int NT>
+void launch_gn_slab(const GNArgs& a, int wgs, hipStream_t s) {
+    hipLaunchKernelGGL((gn_slab_kernel<MAXCH, NT>), dim3(wgs), dim3(NT), 0, s, a);
 }
 
 // ---- LayerNorm: one wave per token row, row held in registers ----------------
@@ -316,7 +472,10 @@ int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream) {
 
 
 // GroupNorm(+SiLU) over the channel-concat of src0[N,H+2,W+2,C0] and src1[N,H+2,W+2,C1]
-// (src1 may be NULL / C1 = 0).  stats: device scratch of N * (1024*G*2 + G*2) floats.
+// (src1 may be NULL / C1 = 0).  stats: device scratch of N * (1024*G*2 + G*2) floats (the two-launch form uses
+// the first N * 64 * G * 2 of them).
+void cfgpp_groupnorm_set_mode(int mode) { g_gn_mode = mode; }
+
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
                        int dst_padded, void* stream) {
@@ -329,21 +488,58 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
     a.src0 = (const half_t*)src0; a.src1 = (const half_t*)src1; a.dst = (half_t*)dst;
     a.gamma = gamma; a.beta = beta;
     a.N = N; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.G = G; a.eps = eps; a.silu = silu;
-    a.dst_padded = dst_padded;
+    a.dst_padded = dst_padded; a.stats = stats; a.nblk = 0; a.gs = 1; a.pix_per_block = 0;
     const int HW = H * W;
-    // aim for >= ~1024 blocks, >= 16 pixels per block, and at most 1024 blocks per sample (scratch bound)
-    int ppb = 64;
-    while (ppb > 16 && (long)N * cdiv(HW, ppb) < 1024) ppb >>= 1;
-    while (cdiv(HW, ppb) > 1024) ppb <<= 1;
+    const int cpg = C / G;
+    // ---- (1) slab kernel: smallest gs (groups per workgroup) whose channel range is whole 16-B chunks ----
+    if (g_gn_mode != 1 && cpg >= 8) {
+        int gs = 0;
+        for (int t = 1; t <= 4; t <<= 1) if (G % t == 0 && (t * cpg) % 8 == 0) { gs = t; break; }
+        const int cpp = gs ? gs * cpg / 8 : 0;
+        // threads = cpp * R, a multiple of 64, at most 960: cpp = 5, 10 -> 320 (x2, x3), 15, 30 -> 960
+        int nt = 0;
+        if (cpp && cpp <= 32) {
+            for (int cand : {320, 640, 960}) {
+                if (cand % cpp) continue;
+                const int chunks_per_thread = cdiv(HW, cand / cpp);
+                if (chunks_per_thread <= 16) { nt = cand; break; }      // 16 chunks = 64 data VGPRs: no spills at 960 threads
+            }
+        }
+        if (nt) {
+            const int R = nt / cpp, cpt = cdiv(HW, R);
+            const int wgs = N * (G / gs);
+            // with few workgroups every CU streams a large slab alone: the two-launch form wins on bandwidth there
+            const bool worth = g_gn_mode == 2 || wgs >= 48;
+            if (worth) {
+                a.gs = gs;
+#define GN_SLAB(NT_)                                                                        \
+                if (nt == NT_) {                                                            \
+                    if (cpt <= 2) launch_gn_slab<2, NT_>(a, wgs, s);                        \
+                    else if (cpt <= 4) launch_gn_slab<4, NT_>(a, wgs, s);                   \
+                    else if (cpt <= 8) launch_gn_slab<8, NT_>(a, wgs, s);                   \
+                    else launch_gn_slab<16, NT_>(a, wgs, s);                                \
+                }
+                GN_SLAB(320) GN_SLAB(640) GN_SLAB(960)
+#undef GN_SLAB
+                CFGPP_HIP_CHECK(hipGetLastError());
+                return 0;
+            }
+        }
+    }
+    // ---- (2) two launches: 64 .. 256 stats blocks per sample (the apply prologue re-reduces them; more of them only
+    // when the batch is too small to fill the CUs otherwise: the VAE at batch 1), >= 16 pixels each ----
+    const int nblk_max = std::max(64, std::min(256, cdiv(768, N)));
+    int ppb = 16;
+    while (cdiv(HW, ppb) > nblk_max) ppb <<= 1;
     a.pix_per_block = ppb;
-    const int nblk = cdiv(HW, ppb);
-    float* part = stats;
-    float* mr = stats + (size_t)N * 1024 * G * 2;
-    a.stats = part; a.mean_rstd = mr;
-    dim3 grid(nblk, N);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, s, part, mr, nblk, G, 1.0f / ((float)(C / G) * (float)HW), eps);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, s, a);
+    a.nblk = cdiv(HW, ppb);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nblk, N), dim3(256), 0, s, a);
+    // apply: aim for >= ~1024 blocks of >= 16 pixels
+    GNArgs b = a;
+    int apb = 64;
+    while (apb > 16 && (long)N * cdiv(HW, apb) < 1024) apb >>= 1;
+    b.pix_per_block = apb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(HW, apb), N), dim3(256), 0, s, b);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -159,13 +159,21 @@ int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w,
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
                        int dst_padded, void* stream);
+/* development / A-B switch of the GroupNorm form: 0 auto, 1 always the two-launch form, 2 the one-launch
+ * slab-in-registers kernel whenever the slab fits (csrc/norm_kernels.hip). */
+void cfgpp_groupnorm_set_mode(int mode);
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream);
-/* V^T contract of cfgpp_op_attention: when d % 32 != 0, row d of every [dp][tok_pad] matrix holds ones
- * (softmax denominator through the PV MFMA).  Call once on the zero-initialised buffer. */
+/* V^T contract of cfgpp_op_attention: vt is [B*heads][dp][tok_pad] with the keys of every 32-key block
+ * permuted - key k lives in column (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1) (bits 2 and 3 swapped), which is
+ * how the QKV projection (cfgpp_op_igemm_heads) writes it; and when d % 32 != 0, row d of every matrix holds
+ * ones (softmax denominator through the PV MFMA): call prepare_vt once on the zero-initialised buffer. */
 int cfgpp_op_attention_prepare_vt(void* vt, int BH, int d, int tok_pad, void* stream);
 int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
+/* A/B switch for head dims padded to 64: 1 (default) LDS-DMA kernel on a 3-stage ring, 2 the same on a 2-stage
+ * ring, 0 the register-staged kernel */
+void cfgpp_attention_set_dma(int mode);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                      int R, int zB, int Cin, int H, int W, int Cout, void* stream);
 /* quant_conv (1x1, 8->8) + DiagonalGaussian posterior on the encoder's 8-channel conv_out (fp32 NCHW). */

@@ -14,6 +14,7 @@ hvt = torch.randn(B * h, dp, kp, device="cuda", dtype=torch.float16)
 if d % 32: hq[:, :, d:] = 0; hk[:, :, d:] = 0; hvt[:, d:, :] = 0
 _lib.check(H.lib().cfgpp_op_attention_prepare_vt(H.P(hvt), B * h, d, kp, H.stream()), "prep")
 o = torch.empty(B, N, h * d, device="cuda", dtype=torch.float16)
+H.lib().cfgpp_attention_set_dma(int(os.environ.get("ATTN_MODE", "1")))
 fn = lambda: _lib.check(H.lib().cfgpp_op_attention(H.P(hq), H.P(hk), H.P(hvt), H.P(o), B, h, d, N, Nk, qp, kp, H.stream()), "attn")
 for _ in range(3): fn()
 torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -168,7 +168,7 @@ def t_big():
     wl = rnd(640, 256, scale=1 / 16, seed=86)
     bl = rnd(640, scale=0.1, seed=87)
     refl = a @ wl.t() + bl
-    for c in (4, 5, 6, 7, 8, 9):     # 7 / 8: 128x160 / 128x320 (partial loader passes); 9: 128x160 with two k-groups
+    for c in (4, 5, 6, 7, 8, 9):     # 7 / 8: 128x160 / 128x320; 9: 128x160 on a 3-stage LDS ring
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
@@ -211,7 +211,7 @@ def t_tail():
     hq, hk, hvt = H.heads_project(a2.to(H.DEV, torch.float16), w2.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
     y = (a2 @ w2.t()).reshape(B, tokens, 3, nheads, C // nheads)
     out["heads_q"] = H.err_stats(hq[:, :tokens, :C // nheads].reshape(B, nheads, tokens, -1), y[:, :, 0].permute(0, 2, 1, 3))
-    out["heads_vt"] = H.err_stats(hvt[:, :C // nheads, :tokens].reshape(B, nheads, -1, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+    out["heads_vt"] = H.err_stats(hvt[:, :C // nheads, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, -1, tokens), y[:, :, 2].permute(0, 2, 3, 1))
     H.lib().cfgpp_igemm_force_config(0)
     H.lib().cfgpp_igemm_set_tail_split(1)
     # plain linear through the split path: M=256, N=256, K=4096 (KT=64)
@@ -281,7 +281,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     out = {}
     out["q"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
     out["k"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
-    out["vt"] = H.err_stats(hvt[:, :d, :tokens].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+    out["vt"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
     out["pad_zero"] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :d, tokens:].abs().sum() == 0 and hvt[:, d + 1:].abs().sum() == 0)
     return out
 

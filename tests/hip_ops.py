@@ -144,6 +144,12 @@ def heads_project(a, w, B, tokens, C, nheads, part0, nparts, q_pad, k_pad):
     return hq, hk, hvt
 
 
+def vt_pos(n):
+    """column of key 0..n-1 in a V^T buffer (bits 2 and 3 of the key index swapped; include/cfgpp.h)"""
+    key = torch.arange(n)
+    return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1)
+
+
 def make_heads(q, k, v):
     """q [B,h,Nq,d], k/v [B,h,Nk,d] (cpu float) -> padded head-major device buffers."""
     B, h, Nq, d = q.shape
@@ -155,7 +161,8 @@ def make_heads(q, k, v):
     hvt = torch.zeros((B * h, dp, k_pad), dtype=torch.float16, device=DEV)
     hq[:, :Nq, :d] = q.reshape(B * h, Nq, d).to(DEV, torch.float16)
     hk[:, :Nk, :d] = k.reshape(B * h, Nk, d).to(DEV, torch.float16)
-    hvt[:, :d, :Nk] = v.reshape(B * h, Nk, d).transpose(1, 2).to(DEV, torch.float16)
+    # V^T contract: within every 32-key block the key index has bits 2 and 3 swapped (include/cfgpp.h)
+    hvt[:, :d, vt_pos(Nk).to(DEV)] = v.reshape(B * h, Nk, d).transpose(1, 2).to(DEV, torch.float16)
     check(lib().cfgpp_op_attention_prepare_vt(P(hvt), B * h, d, k_pad, stream()), "cfgpp_op_attention_prepare_vt")   # ones row when d % 32 != 0
     return hq, hk, hvt, q_pad, k_pad
 

@@ -30,12 +30,12 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def record(name, **kw):
+def record(test, **kw):
     """append measured errors to gpurun_out/parity_r02.jsonl (tolerances are set from these)"""
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "parity_r02.jsonl"), "a") as f:
-            f.write(json.dumps(dict(test=name, **kw)) + "\n")
+            f.write(json.dumps(dict(test=test, **kw)) + "\n")
     except OSError:
         pass
 
