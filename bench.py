@@ -154,25 +154,83 @@ def cpu_baseline(cfg_name, name, nfe, lam, img, limit_s=240):
     return json.loads(lines[-1])
 
 
-def main():
-    args = parse()
-    from cfgpp_amd import dist as D
-    rank, local_rank, world = D.init()
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    kind, name, cfg_name, nfe, lam, B, img, desc = WORKLOADS[args.config]
-    B = args.batch or B
-    nfe = args.nfe or nfe
-    log(f"building engine {cfg_name} max_batch={B}")
-    solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
-    eng = solver.engine
-    log(f"engine ready, device memory {eng.unet.device_bytes() / 1e9:.2f} GB")
+PROFILE_ROUND = "r02"
 
-    # ---- conditioning: rank 0 "encodes" every prompt, ONE broadcast of the packed block ----
+
+def roofline_block(eng, config, B, dev, rnd):
+    """Dominant kernel = the implicit-GEMM conv/linear kernel.  `achieved` = algorithmic FLOPs of its launches in one
+    UNet forward / their summed HIP-event durations on the launch stream (three profiled forwards right after the timed
+    region, `cfgpp_unet_profile`).  Live as well: attention TFLOP/s, and algorithmic GB/s of the HBM-bound families
+    (GroupNorm / LayerNorm at 4 B per element, the fused CFG++ step at 16 B per latent element).  From the committed
+    rocprofv3 PMC passes of the SAME population (UNet-only forwards at this batch with the tiles this build's tuner
+    pins; scripts/pmc_unet.py + scripts/pmc_summary.py -> profiles/<round>/pmc_<config>_b<B>.json): `traffic` (HBM
+    bytes per igemm launch, FETCH_SIZE x2 + WRITE_SIZE per the gfx950 note of the guide) and `mfma_util`
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)) of the igemm and attention kernels."""
+    import re
+    rows = 2 * B
+    z = torch.randn((B, 4, eng.H, eng.W), device=dev)
+    fam = {}
+    gb = {"groupnorm": [0.0, 0.0], "layernorm": [0.0, 0.0]}      # [bytes, seconds]
+    for t in (981.0, 501.0, 21.0):
+        pr = eng.unet.profile(z, t, detail=True)
+        for k in ("igemm", "attention", "norm", "small"):
+            f = fam.setdefault(k, dict(ms=0.0, flops=0.0, launches=pr[k]["launches"]))
+            f["ms"] += pr[k]["ms"]
+            f["flops"] += pr[k]["flops"]
+        for line in pr["detail"].strip().split("\n"):
+            parts = line.split("\t")
+            m = re.match(r"(groupnorm|layernorm) HW=(\d+) C=(\d+)", parts[2]) if len(parts) >= 4 else None
+            if m:
+                gb[m.group(1)][0] += 4.0 * rows * int(m.group(2)) * int(m.group(3))
+                gb[m.group(1)][1] += float(parts[3]) * 1e-6
+    # fused CFG++ step kernel: 16 B per latent element (4 z in, 2 + 2 eps in, 4 z0t out, 4 z out)
+    from cfgpp_amd import engine as E
+    zz = torch.randn((B, 4, eng.H, eng.W), device=dev)
+    z0 = torch.empty_like(zz)
+    eu, ec = (torch.randn((B, 4, eng.H, eng.W), device=dev).half() for _ in range(2))
+    for _ in range(3):
+        E.step_ddim(zz, z0, eu, ec, 0.6, (0.5, 0.8, 0.7, 0.6), False, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        E.step_ddim(zz, z0, eu, ec, 0.6, (0.5, 0.8, 0.7, 0.6), False, True)
+    e1.record()
+    torch.cuda.synchronize()
+    step_s = e0.elapsed_time(e1) / 20 * 1e-3
+    ig = fam["igemm"]
+    ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+    pmc = None
+    pf = os.path.join(ROOT, "profiles", rnd, f"pmc_{config}_b{B}.json")
+    if os.path.exists(pf):
+        try:
+            pmc = json.load(open(pf))
+        except Exception:  # noqa: BLE001
+            pmc = None
+    out = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/linear)", "achieved": round(ach, 1),
+           "peak": PEAK_MFMA_FP16 / 1e12, "unit": "TFLOP/s", "frac": round(ach / (PEAK_MFMA_FP16 / 1e12), 4),
+           "traffic": None if pmc is None else pmc["igemm"].get("hbm_bytes_per_launch"),
+           "traffic_unit": "HBM bytes per igemm launch (rocprofv3 PMC passes over UNet-only forwards at this batch)",
+           "algorithmic_bytes_per_launch": None if pmc is None else pmc["igemm"].get("algorithmic_bytes_per_launch"),
+           "mfma_util": None if pmc is None else {k: pmc[k].get("mfma_util") for k in ("igemm", "attention") if k in pmc},
+           "launches_per_forward": ig["launches"], "avg_launch_us": round(ig["ms"] / 3 / max(ig["launches"], 1) * 1e3, 2),
+           "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in fam.items()},
+           "attention_TFLOPs": round(fam["attention"]["flops"] / (fam["attention"]["ms"] * 1e-3) / 1e12, 1),
+           "hbm_GBps": {"groupnorm": round(gb["groupnorm"][0] / max(gb["groupnorm"][1], 1e-12) / 1e9, 1),
+                        "layernorm": round(gb["layernorm"][0] / max(gb["layernorm"][1], 1e-12) / 1e9, 1),
+                        "cfgpp_step": round(16.0 * zz.numel() / step_s / 1e9, 1),
+                        "note": "algorithmic bytes (GroupNorm / LayerNorm 4 B per element, step 16 B per latent element) / HIP-event time; "
+                                "the step kernel moves %.0f KB per launch and is launch-latency bound" % (16.0 * zz.numel() / 1e3),
+                        "peak": 8000.0},
+           "pmc_source": None if pmc is None else os.path.relpath(pf, ROOT)}
+    return out
+
+
+def prepare_job(solver, cfg, kind, name, B, img, lam, rank, world, dev):
+    """The multi-GPU plumbing of one benchmark job, shared by main() and the world-2 gloo test: rank 0 "encodes" every
+    prompt of the global batch, ONE packed broadcast of the conditioning (RCCL over xGMI on the GPU box), every rank
+    keeps its contiguous shard of B prompts / seeds.  Returns (one_job, global_batch); ``one_job()`` runs the rank's B
+    chains + decode and returns the images.  Nothing is exchanged inside the sampling loop."""
+    from cfgpp_amd import dist as D
     total = B * world
     D_ = cfg.cross_attention_dim
     shapes = [((1, 77, D_), torch.float16), ((total, 77, D_), torch.float16)]
@@ -191,18 +249,43 @@ def main():
     lo, hi = D.shard_range(total, rank, world)
     seeds = [42 + i for i in range(lo, hi)]
     src_img = None
-    if "inversion" in name:      # seeded synthetic source image in [-1, 1]; VAE encode (HIP) is inside the timed job
-        g = torch.Generator().manual_seed(7)
-        src_img = (torch.rand((B, 3, img, img), generator=g) * 2 - 1).to(dev)
+    if "inversion" in name:      # seeded synthetic source images in [-1, 1] (per global prompt index); the VAE encode is inside the timed job
+        imgs = []
+        for i in range(lo, hi):
+            g = torch.Generator().manual_seed(7 + i)
+            imgs.append(torch.rand((1, 3, img, img), generator=g) * 2 - 1)
+        src_img = torch.cat(imgs).to(dev)
 
-    def one_job():
+    def one_job(**extra):
         if kind == "sd":
-            return solver.sample(cfg_guidance=lam, prompt=None, prompt_embeds=(cond[0], cond[1][lo:hi].contiguous()), seeds=seeds)
+            return solver.sample(cfg_guidance=lam, prompt=None, prompt_embeds=(cond[0], cond[1][lo:hi].contiguous()), seeds=seeds, **extra)
         pe = (cond[0], cond[1][lo:hi].contiguous(), cond[2], cond[3][lo:hi].contiguous())
         if "inversion" in name:
             pe = (pe[0], pe[1], pe[1], pe[2], pe[3], pe[3])
-            return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_img=src_img)
-        return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), seeds=seeds)
+            return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), src_img=src_img, **extra)
+        return solver.sample(cfg_guidance=lam, prompt_embeds=pe, target_size=(img, img), seeds=seeds, **extra)
+    return one_job, total
+
+
+def main():
+    args = parse()
+    from cfgpp_amd import dist as D
+    rank, local_rank, world = D.init()
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    kind, name, cfg_name, nfe, lam, B, img, desc = WORKLOADS[args.config]
+    B = args.batch or B
+    nfe = args.nfe or nfe
+    log(f"building engine {cfg_name} max_batch={B}")
+    solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
+    eng = solver.engine
+    log(f"engine ready, device memory {eng.unet.device_bytes() / 1e9:.2f} GB")
+
+    one_job, total = prepare_job(solver, cfg, kind, name, B, img, lam, rank, world, dev)
 
     for i in range(args.warmup):
         out = one_job()
@@ -235,35 +318,7 @@ def main():
                    "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
     }
     if rank == 0 and not args.no_profile:
-        # dominant kernel = the implicit-GEMM conv/linear kernel: algorithmic FLOPs of its launches in one
-        # forward / their summed HIP-event durations on the launch stream (a profile pass right after the timed region)
-        z = torch.randn((B, 4, eng.H, eng.W), device=dev)
-        agg = None
-        for t in (981.0, 501.0, 21.0):
-            pr = eng.unet.profile(z, t)
-            if agg is None:
-                agg = pr
-            else:
-                for k in agg:
-                    agg[k]["ms"] += pr[k]["ms"]
-                    agg[k]["flops"] += pr[k]["flops"]
-        # HBM traffic of the same kernel family from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-        # separate --pmc runs, scripts/pmc_traffic.py); measured once per round and committed under profiles/.
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01", f"pmc_traffic_{args.config}_b{B}.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf))["igemm"]["hbm_bytes_per_launch"]
-            except Exception:  # noqa: BLE001
-                traffic = None
-        ig = agg["igemm"]
-        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/linear)", "achieved": round(ach, 1),
-                              "peak": PEAK_MFMA_FP16 / 1e12, "unit": "TFLOP/s", "frac": round(ach / (PEAK_MFMA_FP16 / 1e12), 4),
-                              "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, incl. the VAE's igemm launches)", "launches_per_forward": ig["launches"],
-                              "avg_launch_us": round(ig["ms"] / 3 / max(ig["launches"], 1) * 1e3, 2),
-                              "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in agg.items()},
-                              "attention_TFLOPs": round(agg["attention"]["flops"] / (agg["attention"]["ms"] * 1e-3) / 1e12, 1)}
+        result["roofline"] = roofline_block(eng, args.config, B, dev, PROFILE_ROUND)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (child process, bounded) ...")
         try:

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "cfgpp_unet_set_context": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "cfgpp_unet_forward": (_I, [_P, _P, _I, _I, _F, _P, _I, _P]),
     "cfgpp_unet_profile": (_I, [_P, _P, _I, _I, _F, _P, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, _L]),
+    "cfgpp_unet_tuning": (_I, [_P, _I, C.POINTER(C.c_int), _I, _I]),
     "cfgpp_unet_flops": (C.c_double, [_P, _I]),
     "cfgpp_unet_device_bytes": (C.c_double, [_P]),
     "cfgpp_vae_create": (_P, [_I, _I, _I, _F, _I]),

@@ -46,8 +46,22 @@ struct AttnArgs {
     int nq, nk_valid;     // real query / key counts
     int q_tok_pad, k_tok_pad;
     int o_ld;             // heads*d
+    int nqb;              // query blocks (of 128 queries) per batch*head; grid = nqb * B * heads workgroups
     float scale_log2e;    // d^-0.5 * log2(e)
 };
+
+// Workgroup -> (query block, batch*head).  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never
+// correctness), and every XCD has its own 4 MiB L2.  All query blocks of one (batch, head) read the same K / V^T
+// (1 MB at N = 4096): with the natural order they are spread over all 8 XCDs and every L2 has to hold the K / V^T
+// of EVERY head in flight (24 heads x 1 MB >> 4 MiB), so K / V^T tiles keep coming from HBM / Infinity Cache
+// (~4 GB of fabric traffic per launch instead of 128 MB).  The remap hands each XCD a contiguous range of
+// (batch*head, query block) pairs: the ~3 heads an XCD works on at a time stay L2-resident.
+__device__ __forceinline__ void attn_block_map(int nqb, int& qb, int& bh) {
+    const int T = gridDim.x, bid = blockIdx.x;
+    const int q = T >> 3, r = T & 7, xcd = bid & 7, idx = bid >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bh = w / nqb; qb = w - bh * nqb;
+}
 
 template <int D16, int DT, bool ONES, int QT>
 __global__ void __launch_bounds__(256)
@@ -64,8 +78,9 @@ attn_kernel(const AttnArgs a) {
     // QT = 2 (240-256 VGPRs, 2 waves/SIMD): +2 % at d = 40, -11 % at d = 64 (N = 4096), so QT = 1 ships.
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * (128 * QT) + wid * (32 * QT);
+    int qb, bh;
+    attn_block_map(a.nqb, qb, bh);
+    const int q0 = qb * (128 * QT) + wid * (32 * QT);
     const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
     const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
     const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
@@ -270,8 +285,9 @@ attn64_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    int qb, bh;
+    attn_block_map(a.nqb, qb, bh);
+    const int q0 = qb * 128 + wid * 32;
     const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
     const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
     const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
@@ -511,7 +527,8 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     a.heads = heads; a.d = d; a.nq = nq; a.nk_valid = nk; a.q_tok_pad = q_tok_pad; a.k_tok_pad = k_tok_pad;
     a.o_ld = heads * d;
     a.scale_log2e = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
-    dim3 grid(cdiv(nq, 128), B * heads);
+    a.nqb = cdiv(nq, 128);
+    dim3 grid(a.nqb * B * heads);
     hipStream_t s = (hipStream_t)stream;
     const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
     const bool ones = (d % 32) != 0;

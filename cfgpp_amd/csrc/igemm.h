@@ -38,6 +38,8 @@ struct IGemmArgs {
     int part0;                // which part column 0 belongs to: 0=Q, 1=K (K,V projection)
     int part_width;           // C: columns per part
     int head_dim, head_dim_pad, heads;
+    int vt_linear;            // 0: V^T columns in the attention kernel's permuted key order (cfgpp_vt_pos); 1: natural order
+                              // (the VAE consumes V^T as the weight operand of a plain GEMM)
     int tok_pad;              // padded token count of K rows / V^T columns (>= rows_per_batch)
     int q_tok_pad;            // padded token count of Q rows
     // ---- tile scheduling (filled by igemm_launch) ----

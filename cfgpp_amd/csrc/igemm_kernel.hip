@@ -128,7 +128,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                     }
                     const long bh = (long)b * p.heads + head;
                     if (part == 2) {
-                        half_t* dst = p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + cfgpp_vt_pos(tok);
+                        half_t* dst = p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + (p.vt_linear ? tok : cfgpp_vt_pos(tok));
 #pragma unroll
                         for (int k = 0; k < 4; ++k) dst[(long)k * p.tok_pad] = (half_t)v[k];
                     } else {
@@ -773,6 +773,9 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 7: return launch_cfg<4, 1, 32, 160, true>(a, stream);     // 128 x 160, 4 waves, 2 workgroups / CU
         case 8: return launch_cfg<4, 2, 32, 160, true>(a, stream);     // 128 x 320, 8 waves
         case 9: return launch_cfg<4, 1, 32, 160, true, 3>(a, stream);  // 128 x 160, 4 waves, 3-stage ring, ONE workgroup / CU (256-tile grids)
+        // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
+        // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too
+        case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -825,7 +828,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const bool valid = (h == 1 || h == 4 || h == 6 || h == 10 || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     return launch_config(cfg, a, stream);

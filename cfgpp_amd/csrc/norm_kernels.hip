@@ -262,7 +262,7 @@ gn_stats_kernel(GNArgs a) {
 }
 
 // Pass 2: apply.  Prologue: the fixed-order reduction of the nblk (<= 256) stats blocks to (mean, rstd) per group,
-// one wave per 8 groups (lane l reads block l, xor-shuffle tree), recomputed by every workgroup (16 KB of L2 reads).
+// recomputed by every workgroup (16 .. 64 KB of L2 reads).
 __global__ void __launch_bounds__(256)
 gn_apply_kernel(GNArgs a) {
     __shared__ float s_mean[64], s_rstd[64];
@@ -274,22 +274,28 @@ gn_apply_kernel(GNArgs a) {
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
     {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const float inv_cnt = 1.0f / ((float)cpg * (float)HW);
-        for (int g = wid; g < a.G; g += 4) {
+        // thread (g = t % G, slice = t / G) sums stats blocks slice, slice + NSL, ... (independent loads); thread g then adds
+        // the NSL slices in order: a fixed summation order, one round of memory latency
+        __shared__ float s_ps[8][64][2];
+        const int NSL = 256 / a.G < 8 ? 256 / a.G : 8;               // slices (G = 32: 8)
+        const int g = threadIdx.x % a.G, sl = threadIdx.x / a.G;
+        if (sl < NSL) {
             float s = 0.f, q = 0.f;
-            for (int b = lane; b < a.nblk; b += 64) {
+            for (int b = sl; b < a.nblk; b += NSL) {
                 const float* p = a.stats + (((long)n * a.nblk + b) * a.G + g) * 2;
                 s += p[0]; q += p[1];
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-            if (lane == 0) {
-                const float dm = s * inv_cnt;                      // mean - pivot
-                float var = q * inv_cnt - dm * dm;                 // benign: |dm| is a few sigma at most
-                var = var < 0.f ? 0.f : var;
-                s_mean[g] = gn_pivot(a, n, g * cpg) + dm; s_rstd[g] = rsqrtf(var + a.eps);
-            }
+            s_ps[sl][g][0] = s; s_ps[sl][g][1] = q;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < a.G) {
+            float s = 0.f, q = 0.f;
+            for (int k = 0; k < NSL; ++k) { s += s_ps[k][g][0]; q += s_ps[k][g][1]; }
+            const float inv_cnt = 1.0f / ((float)cpg * (float)HW);
+            const float dm = s * inv_cnt;                      // mean - pivot
+            float var = q * inv_cnt - dm * dm;                 // benign: |dm| is a few sigma at most
+            var = var < 0.f ? 0.f : var;
+            s_mean[g] = gn_pivot(a, n, g * cpg) + dm; s_rstd[g] = rsqrtf(var + a.eps);
         }
     }
     __syncthreads();

@@ -549,6 +549,24 @@ int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
     return rc;
 }
 
+// Export (set = 0) / import (set = 1) the tile configs the in-situ tuning pinned for batch `rows`: one int per
+// igemm launch of the plan, in plan order.  Lets a profiled run (rocprofv3 --pmc) replay exactly the tiles of the
+// un-profiled run without timing passes of its own.  Returns the number of hint slots, or < 0 on error.
+int cfgpp_unet_tuning(cfgpp_unet* u, int rows, int* hints, int cap, int set) {
+    CFGPP_REQUIRE(u && u->finalized && hints && rows > 0, "unet_tuning: bad args");
+    const int n = (int)u->cfg_hints.size();
+    CFGPP_REQUIRE(cap >= n, "unet_tuning: buffer of %d for %d launches", cap, n);
+    if (set) {
+        u->tuned_by_rows[rows] = std::vector<int>(hints, hints + n);
+        if (u->tuned_rows == rows) u->tuned_rows = 0;      // re-install on the next forward
+        return n;
+    }
+    auto it = u->tuned_by_rows.find(rows);
+    if (it == u->tuned_by_rows.end()) { cfgpp_set_error("unet_tuning: batch %d has not been tuned", rows); return -3; }
+    std::copy(it->second.begin(), it->second.end(), hints);
+    return n;
+}
+
 double cfgpp_unet_flops(cfgpp_unet* u, int rows) {
     if (!u || !u->finalized) return 0.0;
     return 2.0 * (u->macs_per_row + u->attn_macs_per_row) * rows;

@@ -197,6 +197,7 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
             a.a0 = v->tok_a; a.C0 = C; a.amode = 0; a.w = wqkv; a.N = 3 * C; a.K = C; a.bias = bqkv; a.epi = EPI_HEADS;
             a.rows_per_batch = T; a.hq = v->hq; a.hk = v->hk; a.hvt = v->hvt; a.part0 = 0; a.part_width = C;
             a.head_dim = C; a.head_dim_pad = C; a.heads = 1; a.tok_pad = T; a.q_tok_pad = T;
+            a.vt_linear = 1;        // V^T is the weight operand of the P V GEMM below: natural key order
             v->macs_per_row += (double)T * 3 * C * C;
             P.ops->push_back([a, T](hipStream_t s, int rows) mutable { IGemmArgs b = a; b.M = rows * T; return igemm_launch(b, s); });
             if (tagged) v->tag(0, (double)T * 3 * C * C, "vae qkv");

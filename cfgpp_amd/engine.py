@@ -240,6 +240,21 @@ class HipUNet:
             out["detail"] = buf.value.decode()
         return out
 
+    def export_tuning(self, rows: Optional[int] = None):
+        """tile config pinned per igemm launch by the in-situ tuning at this batch (list of ints, plan order)"""
+        rows = self.rows if rows is None else int(rows)
+        buf = (C.c_int * 4096)()
+        n = self.lib.cfgpp_unet_tuning(self._h, rows, buf, 4096, 0)
+        if n < 0:
+            raise CfgppError("cfgpp_unet_tuning: " + _lib.last_error())
+        return [int(buf[i]) for i in range(n)]
+
+    def import_tuning(self, hints, rows: int):
+        buf = (C.c_int * len(hints))(*[int(h) for h in hints])
+        n = self.lib.cfgpp_unet_tuning(self._h, int(rows), buf, len(hints), 1)
+        if n < 0:
+            raise CfgppError("cfgpp_unet_tuning: " + _lib.last_error())
+
     def flops(self, rows: int) -> float:
         return float(self.lib.cfgpp_unet_flops(self._h, int(rows)))
 

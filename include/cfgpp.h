@@ -127,6 +127,11 @@ int cfgpp_unet_profile(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
                        void* stream, double* out_ms, double* out_flops, int* out_launches,
                        char* detail /* optional: one text line per launch */, long detail_cap);
 
+/* Export (set = 0) / import (set = 1) the per-launch tile configs pinned by the in-situ tuning at batch `rows`
+ * (one int per implicit-GEMM launch, plan order); returns the number of slots.  A profiled run imports what the
+ * un-profiled run chose, so PMC passes see the same kernels without timing passes of their own. */
+int cfgpp_unet_tuning(cfgpp_unet* u, int rows, int* hints, int cap, int set);
+
 /* Algorithmic FLOPs (2*MAC over conv/linear/attention matmuls) of one forward at `rows`. */
 double cfgpp_unet_flops(cfgpp_unet* u, int rows);
 /* Bytes of device memory held (weights + activations). */

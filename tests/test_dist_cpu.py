@@ -61,3 +61,69 @@ def test_shard_range_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- bench.py's own multi-GPU flow (broadcast -> shard -> solver.sample -> gather) on CPU, world 2, gloo ----
+def _bench_flow(kind, rank, world, B):
+    """what bench.main() does per rank, with a CPU mock engine in place of the HIP engine"""
+    import types
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from _stub_env import pointwise_eps
+    from mock_engine import MockEngine, StubVAE
+    from cfgpp_amd.unet_config import TINY_SD, TINY_XL
+
+    def unet(z, t, ehs, te, ti):
+        return pointwise_eps(z, torch.as_tensor(float(t)).reshape(1), ehs, te, ti)
+    sc = types.SimpleNamespace(num_sampling=3)
+    if kind == "sd":
+        from cfgpp_amd.latent_diffusion import get_solver
+        cfg, name = TINY_SD, "ddim_cfg++"
+    else:
+        from cfgpp_amd.latent_sdxl import get_solver
+        cfg, name = TINY_XL, "ddim_cfg++"
+    solver = get_solver(name, solver_config=sc, device="cpu", unet_config=cfg, max_batch=B, latent_hw=(8, 8),
+                        engine=MockEngine(unet, (8, 8)), vae=StubVAE(cfg.vae_scale))
+    one_job, total = bench.prepare_job(solver, cfg, kind, name, B, 64, 0.6, rank, world, torch.device("cpu"))
+    out = one_job(return_latents=True)
+    z = out[0] if kind == "sd" else out
+    img = one_job()                              # the decode + D2H leg as well
+    assert img.shape[0] == B and bool(torch.isfinite(img).all())
+    return z.float(), total
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cfgpp_amd import dist as D
+    r, lr, w = D.init("gloo")
+    res = {}
+    for kind in ("sd", "xl"):
+        z, total = _bench_flow(kind, r, w, 2)
+        allz = D.gather_rows(z, [2] * w)
+        dt = D.max_over_ranks(0.5 + r, torch.device("cpu"))
+        res[kind] = (None if allz is None else allz.numpy(), total, dt)
+    D.barrier()
+    q.put((r, res))
+
+
+def test_world2_bench_flow_equals_single_process():
+    """`bench.py --gpus 2` plumbing: every rank samples its own prompt / seed shard from ONE broadcast conditioning
+    block; the gathered latents equal the single-process run of the same global batch, chain by chain."""
+    world, port = 2, 29547
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for kind in ("sd", "xl"):
+        got, total, dt = res[0][kind]
+        assert res[1][kind][0] is None and total == 4 and dt == res[1][kind][2] == 1.5
+        ref, _ = _bench_flow(kind, 0, 1, 4)      # world 1, the whole global batch in one process
+        assert torch.equal(torch.from_numpy(got), ref), kind

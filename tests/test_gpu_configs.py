@@ -145,8 +145,9 @@ def _xl_pair(name, nfe, B, hw=16):
     return hip, ref, cfg
 
 
-XL_CASES = [("ddim_cfg++", 20, 0.6, 5e-3), ("ddim_cfg++_lightning", 4, 1.0, 5e-3), ("dpm++_2m_cfgpp", 10, 0.6, 5e-3),
-            ("ddim", 8, 5.0, 1e-2), ("euler_cfg++", 8, 0.6, 5e-3)]
+# tolerance = ~2x the chain rel-L2 measured on the MI355X (profiles/r02/parity_r02.jsonl): 6.0e-4, 5.1e-4, 2.2e-3, 1.6e-3, 8.7e-4
+XL_CASES = [("ddim_cfg++", 20, 0.6, 1.5e-3), ("ddim_cfg++_lightning", 4, 1.0, 1.5e-3), ("dpm++_2m_cfgpp", 10, 0.6, 5e-3),
+            ("ddim", 8, 5.0, 4e-3), ("euler_cfg++", 8, 0.6, 2e-3)]
 
 
 @pytest.mark.parametrize("name,nfe,lam,tol", XL_CASES)
@@ -233,8 +234,8 @@ def test_sd_invert_with_hip_vae_vs_oracle():
     assert a.dtype == torch.float16 and rel < 1e-2, rel
 
 
-@pytest.mark.parametrize("name,lam", [("euler_a_cfg++", 0.6), ("dpm++_2s_a_cfg++", 0.6), ("euler_a", 7.5)])
-def test_ancestral_solver_chain_vs_oracle_pinned_noise(name, lam):
+@pytest.mark.parametrize("name,lam,tol", [("euler_a_cfg++", 0.6, 2e-3), ("dpm++_2s_a_cfg++", 0.6, 2e-3), ("euler_a", 7.5, 1e-2)])
+def test_ancestral_solver_chain_vs_oracle_pinned_noise(name, lam, tol):
     """ancestral samplers with the injected noise pinned on both sides (the reference draws it from the device RNG)"""
     need_gpu()
     from cfgpp_amd.latent_diffusion import get_solver
@@ -259,7 +260,7 @@ def test_ancestral_solver_chain_vs_oracle_pinned_noise(name, lam):
     b = ref.sample(cfg_guidance=lam, prompt_embeds=(uc.cpu(), c.cpu()), seeds=[3, 4], return_latents=True)[1]
     rel = rel_l2(a, b)
     record("ancestral_chain", name=name, rel_l2=rel)
-    assert torch.isfinite(a.float()).all() and rel < 1e-2, f"{name}: rel-L2 {rel:.3e}"
+    assert torch.isfinite(a.float()).all() and rel < tol, f"{name}: rel-L2 {rel:.3e}"      # measured 7.1e-4, 8.8e-4, 4.2e-3
 
 
 # ------------------------------------------------------------------ the benchmark's own sizes
@@ -305,7 +306,7 @@ def test_real_sd15_batch8_chain_4_steps():
     ref, _ = O.sample_ddim(unet, zT, SchedulerTables(nfe), lam, cfgpp=True, semantics="cuda")
     rel = rel_l2(a, ref)
     record("real_sd15_b8_chain", nfe=nfe, rel_l2=rel, cpu_ref_s=round(time.time() - t0, 1))
-    assert torch.isfinite(a).all() and rel < 5e-3, f"chain rel-L2 {rel:.3e}"
+    assert torch.isfinite(a).all() and rel < 1e-3, f"chain rel-L2 {rel:.3e}"      # measured 4.1e-4
 
 
 ATTN_CASES = [(1, 2, 4096, 4096, 40), (1, 2, 4096, 4096, 64), (2, 3, 1024, 1024, 64), (1, 2, 4096, 77, 40), (1, 2, 4096, 77, 64),
@@ -326,7 +327,7 @@ def test_attention_at_unet_sizes(B, h, Nq, Nk, d):
     got = H.attention(hq, hk, hvt, B, h, d, Nq, Nk, qp, kp)
     st = H.err_stats(got, ref)
     record("attention", B=B, h=h, Nq=Nq, Nk=Nk, d=d, **st)
-    assert st["finite"] and st["rel_l2"] < 1.5e-3, st
+    assert st["finite"] and st["rel_l2"] < 1.2e-3, st           # measured 4.6e-4 .. 5.7e-4
 
 
 def test_attention_online_softmax_rescale_branch():
@@ -382,4 +383,4 @@ def test_groupnorm_large_mean_small_variance():
         st = H.err_stats(got, ref)
         out[f"{C}x{Hh}"] = st
         record("groupnorm_large_mean", C=C, hw=Hh, mean=mean, sigma=sig, **st)
-        assert st["finite"] and st["rel_l2"] < 3e-3, (C, Hh, st)
+        assert st["finite"] and st["rel_l2"] < 6e-4, (C, Hh, st)       # measured 2.1e-4 (fp16 output rounding)

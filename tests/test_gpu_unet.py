@@ -1,6 +1,6 @@
 """-m gpu: the HIP UNet and the whole sampling loop against the fp32 CPU oracle on identical
-seeds.  Stated tolerance (fp16 storage, fp32 accumulate; calibrated: a single forward lands at
-rel-L2 ~1e-3, a 50-step chain at a few 1e-3): per-forward eps rel-L2 <= 5e-3, chain x0 rel-L2 <= 2e-2."""
+seeds.  Stated tolerance (fp16 storage, fp32 accumulate; measured: a single forward lands at rel-L2 1.0e-3,
+chains at 4e-4 .. 2e-3): per-forward eps rel-L2 <= 2.5e-3, chain x0 rel-L2 <= 6e-3 (gpurun_out/parity_r02.jsonl)."""
 import types
 
 import pytest
@@ -8,8 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-EPS_REL = 5e-3
-CHAIN_REL = 2e-2
+EPS_REL = 2.5e-3
+CHAIN_REL = 6e-3
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +23,9 @@ def diag():
 @pytest.mark.parametrize("cfg_name,R,hw", [("tiny_sd", 4, 16), ("tiny_xl", 2, 16), ("tiny_sd", 6, 24), ("sd15", 2, 64), ("sdxl", 2, 32)])
 def test_unet_forward_vs_oracle(diag, cfg_name, R, hw):
     r = diag.unet_case(cfg_name, R, hw)
+    from test_gpu_configs import record
     for k in ("t981", "t1"):
+        record("unet_forward", cfg=cfg_name, rows=R, hw=hw, t=k, rel_l2=r[k]["rel_l2"])
         assert r[k]["finite"] and r[k]["rel_l2"] < EPS_REL, f"{cfg_name} {k}: {r[k]}"
 
 
@@ -76,6 +78,8 @@ def test_sd_chain_vs_oracle(name, nfe, lam):
     kw["prompt_embeds"] = (uc.cpu(), c.cpu())
     b = ref.sample(**kw)[0].float()
     rel = float((a - b).norm() / b.norm())
+    from test_gpu_configs import record
+    record("sd_chain", name=name, nfe=nfe, rel_l2=rel)
     assert torch.isfinite(a).all() and rel < CHAIN_REL, f"{name}: chain rel-L2 {rel:.3e}"
 
 
