@@ -86,6 +86,7 @@ PROTOTYPES = {
     "cfgpp_igemm_set_big_tiles": (None, [_I]),
     "cfgpp_igemm_set_tail_split": (None, [_I]),
     "cfgpp_igemm_set_autotune": (None, [_I]),
+    "cfgpp_igemm_set_n_major": (None, [_I]),
     "cfgpp_groupnorm_set_mode": (None, [_I]),
     "cfgpp_attention_set_dma": (None, [_I]),
 }

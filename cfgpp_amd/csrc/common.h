@@ -15,6 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- error plumbing (no exception crosses the C ABI) -----------------------
 void cfgpp_set_error(const char* fmt, ...);
+int cfgpp_claim_device(int device_id);      // 0, or -1 (+ error) when the process already drives another device
 #define CFGPP_HIP_CHECK(expr)                                                         \
     do {                                                                              \
         hipError_t _e = (expr);                                                       \

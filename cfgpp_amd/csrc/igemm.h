@@ -49,6 +49,7 @@ struct IGemmArgs {
     int cfg_hint;             // 0 = heuristic; 1/4/5/6 = tile config pinned by the engine's in-situ tuning pass
     int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
     int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
+    int n_major;              // 1: N-major tile walk (weight slabs stay L2-resident): weight-heavy launches
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);

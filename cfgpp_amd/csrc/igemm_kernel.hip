@@ -294,9 +294,18 @@ igemm_kernel(const IGemmArgs p) {
         wg = p.n_main + b2 / p.ksplit;
         ksl = b2 - (b2 / p.ksplit) * p.ksplit;
     }
-    // (An N-major walk - weight tiles shared inside an XCD instead of activation rows - was measured: fewer
-    // fabric bytes on the weight-heavy levels but 0.3-1.6 % slower end to end, so the order stays M-major.)
-    const int tile_m = wg / ntn, tile_n = wg - tile_m * ntn;
+    // Tile walk.  M-major (consecutive tiles share activation rows; an XCD's L2 streams every weight slab once): right
+    // when the activations are the larger operand.  N-major (consecutive tiles share a weight slab, which then stays in
+    // the XCD's L2 while the - smaller - activation matrix is what every XCD streams): right for the weight-heavy
+    // launches (GEGLU at M = 4096: 26 MB of weights vs 10 MB of activations; PMC showed 56 % L2 misses M-major).
+    // The launcher picks by operand bytes (IGemmArgs::n_major); the result does not depend on it.
+    int tile_m, tile_n;
+    if (p.n_major && !is_tail) {
+        const int ntm = (p.M + BM - 1) / BM;
+        tile_n = wg / ntm; tile_m = wg - tile_n * ntm;
+    } else {
+        tile_m = wg / ntn; tile_n = wg - tile_m * ntn;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -640,7 +649,8 @@ igemm_kernel(const IGemmArgs p) {
                 for (int r = 0; r < 16; ++r) ws[(long)((i * NT + j) * 16 + r) * NTHR] = acc[i][j][r];
         return;
     }
-    if (p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
+    constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
+    if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
         igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)));
         return;
@@ -698,6 +708,8 @@ extern "C" void cfgpp_igemm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 
 static int g_big_tiles = 1;
 extern "C" void cfgpp_igemm_set_big_tiles(int on) { g_big_tiles = on ? 1 : 0; }
 static int g_tail_split = 1;                        // 1 = K-split tiny grids with long K (8x8-level convs)
+static int g_n_major = -1;                          // tile walk: -1 = by operand bytes, 0 = always M-major, 1 = always N-major
+extern "C" void cfgpp_igemm_set_n_major(int mode) { g_n_major = mode; }
 
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
@@ -716,6 +728,10 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
     a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.staged_epi = g_staged_epi;
+    {   // weight bytes vs unique activation bytes (a 3x3 conv re-reads each pixel through L2: its A operand is M x Cin)
+        const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
+        a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && cdiv(a.N, BN) >= 8)) ? 1 : 0;
+    }
     // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
     // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
     // finishes them.  S is chosen so that T*S fills the resident slots once or twice.
@@ -774,7 +790,8 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 8: return launch_cfg<4, 2, 32, 160, true>(a, stream);     // 128 x 320, 8 waves
         case 9: return launch_cfg<4, 1, 32, 160, true, 3>(a, stream);  // 128 x 160, 4 waves, 3-stage ring, ONE workgroup / CU (256-tile grids)
         // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
-        // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too
+        // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
+        // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
@@ -828,7 +845,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || h == 10 || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     return launch_config(cfg, a, stream);

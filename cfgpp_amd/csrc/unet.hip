@@ -126,6 +126,7 @@ cfgpp_unet* cfgpp_unet_create(const cfgpp_unet_config* cfg, int device_id) {
         cfgpp_set_error("unet_create: no HIP device %d (found %d) - the HIP path has no CPU fallback", device_id, ndev);
         return nullptr;
     }
+    if (cfgpp_claim_device(device_id)) return nullptr;
     if (hipSetDevice(device_id) != hipSuccess) { cfgpp_set_error("unet_create: hipSetDevice failed"); return nullptr; }
     cfgpp_unet* u = new cfgpp_unet();
     u->cfg = *cfg; u->device = device_id; u->max_rows = cfg->max_rows; u->norm_groups = cfg->norm_groups;

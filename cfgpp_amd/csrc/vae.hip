@@ -88,6 +88,7 @@ cfgpp_vae* cfgpp_vae_create(int latent_h, int latent_w, int max_batch, float sca
         cfgpp_set_error("vae_create: no HIP device %d - the HIP path has no CPU fallback", device_id);
         return nullptr;
     }
+    if (cfgpp_claim_device(device_id)) return nullptr;
     cfgpp_vae* v = new cfgpp_vae();
     v->h = latent_h; v->w = latent_w; v->max_rows = max_batch; v->norm_groups = 32; v->scaling = scaling_factor; v->device = device_id;
     // conv_in weight lives in the fp32 table like the UNet's

@@ -28,10 +28,10 @@ class HipEngine:
         if dev.type != "cuda":
             raise CfgppError(f"HipEngine cannot run on device '{dev}': the HIP path has no CPU fallback")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
-        torch.cuda.set_device(self.device)
         self.cfg = cfg
         self.max_batch = int(max_batch)
-        self.unet = E.HipUNet(cfg, max_rows=2 * self.max_batch, sample_hw=latent_hw, device=self.device.index)
+        with torch.cuda.device(self.device):          # the caller's current device is left as it was
+            self.unet = E.HipUNet(cfg, max_rows=2 * self.max_batch, sample_hw=latent_hw, device=self.device.index)
         if weights == "synthetic":
             items = synth_state_dict_iter(cfg, weight_seed)
         elif isinstance(weights, str):

@@ -270,7 +270,12 @@ class SDXLLightning(SDXL):
     def __init__(self, solver_config, base_model_key: str = "stabilityai/stable-diffusion-xl-base-1.0",
                  light_model_ckpt: str = "ckpt/sdxl_lightning_4step_unet.safetensors", dtype=torch.float16,
                  device="cuda", **kwargs):
+        # the reference swaps the Lightning UNet state dict into the base pipeline (latent_sdxl.py:378-390): here the
+        # checkpoint file - when it exists - IS the engine's UNet weights (no checkpoints exist offline: synthetic then)
         self.light_model_ckpt = light_model_ckpt
+        import os
+        if kwargs.get("unet_weights") is None and kwargs.get("engine") is None and light_model_ckpt and os.path.exists(light_model_ckpt):
+            kwargs["unet_weights"] = light_model_ckpt
         SDXL.__init__(self, solver_config, model_key=base_model_key, dtype=dtype, device=device, **kwargs)
 
 

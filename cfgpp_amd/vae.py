@@ -101,6 +101,20 @@ def synth_vae_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
     return sd
 
 
+# older AutoencoderKL checkpoints (e.g. the published SD1.5 VAE) name the mid-block attention projections
+# query / key / value / proj_attn - sometimes as 1x1-conv-shaped [C, C, 1, 1] weights, which the engine accepts
+# (same element count); diffusers >= 0.15 renames them on load exactly like this
+_DEPRECATED_ATTN = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+
+
+def _canonical_vae_key(k: str) -> str:
+    if ".attentions." in k:
+        for old, new in _DEPRECATED_ATTN.items():
+            if old in k:
+                return k.replace(old, new)
+    return k
+
+
 class HipVAE:
     """VAE whose ``decode`` and ``encode`` run on libcfgpp_hip.so (no MIOpen, no torch conv).
     ``with_encoder=False`` skips loading the encoder weights (text-to-image solvers never encode)."""
@@ -124,6 +138,7 @@ class HipVAE:
         if not self._h:
             raise CfgppError("cfgpp_vae_create failed: " + _lib.last_error())
         for k, v in self._sd.items():
+            k = _canonical_vae_key(k)
             if not with_encoder and (k.startswith("encoder.") or k.startswith("quant_conv.")):
                 continue
             t = v.detach().cpu().contiguous()

@@ -15,7 +15,9 @@
  * work is enqueued asynchronously on the hipStream_t passed as `void* stream`
  * and nothing synchronises (one exception: the tile-tuning passes of the first
  * forward at a batch size, see cfgpp_igemm_set_autotune); return 0 on success, < 0 on error with a message in
- * cfgpp_last_error() (thread-local).  One context per device; not thread-safe.
+ * cfgpp_last_error() (thread-local).  Not thread-safe.  ONE DEVICE PER PROCESS (the torchrun layout, one rank per
+ * GPU): launcher state (K-split workspace, tuning switches) is process-global, and cfgpp_unet_create /
+ * cfgpp_vae_create refuse a device other than the first one the process used.
  */
 #ifndef CFGPP_H
 #define CFGPP_H
@@ -206,7 +208,10 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
 void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128; 11..13 = register-staged 1..3 */
-void cfgpp_igemm_set_tail_split(int on); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
+void cfgpp_igemm_set_tail_split(int on);
+/* tile walk of the implicit GEMM: -1 (default) by operand bytes, 0 always M-major, 1 always N-major; the result
+ * does not depend on it */
+void cfgpp_igemm_set_n_major(int mode); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins
  * the fastest; results are bit-identical across candidates, K-split launches stay rule-based.  0: fixed heuristic. */

@@ -8,6 +8,7 @@ SH = {"conv_l0_640in": ("conv", 16, 64, 640, 320), "conv_l0_320": ("conv", 16, 6
 kind, R, hw, Cin, N = SH[sys.argv[1]]; cfg = int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 M = R * hw * hw
 H.lib().cfgpp_igemm_force_config(cfg)
+H.lib().cfgpp_igemm_set_n_major(int(os.environ.get("N_MAJOR", "-1")))
 if kind == "conv":
     K = 9 * Cin
     x = torch.randn(R, hw + 2, hw + 2, Cin, device="cuda", dtype=torch.float16)
