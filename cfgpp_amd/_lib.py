@@ -62,6 +62,7 @@ PROTOTYPES = {
     "cfgpp_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),
     "cfgpp_vae_finalize": (_I, [_P]),
     "cfgpp_vae_decode": (_I, [_P, _P, _P, _I, _P]),
+    "cfgpp_vae_decode_image": (_I, [_P, _P, _P, _I, _P]),
     "cfgpp_vae_encode": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "cfgpp_vae_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_encode_flops": (C.c_double, [_P, _I]),
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_vae_posterior": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "cfgpp_op_conv_out": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_conv_out_ex": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
     "cfgpp_op_sinusoid": (_I, [_P, _F, _P, _I, _I, _I, _I, _P]),
     "cfgpp_op_skinny_gemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_f16_to_f32_rows": (_I, [_P, _P, _I, _I, _I, _I, _P]),

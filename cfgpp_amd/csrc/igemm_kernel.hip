@@ -258,14 +258,102 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
     }
 }
 
+// EPI_HEADS through LDS.  The plain epilogue above scatters 8-byte pieces (Q, K) and - for V^T, which is stored
+// transposed - single halves (4 two-byte stores per lane and accumulator group): measured, the QKV projection ran at
+// 664 TF/s where the same GEMM with a plain store runs at 930.  Here every 32-token x 32-column accumulator sub-tile is
+// staged in a 32 x (64 + 16)-byte LDS block - row-major [token][column] for Q / K columns, TRANSPOSED
+// [column = head dim][token position] for V columns (positions = the attention kernel's permuted key order) - and
+// leaves as 16-byte pieces: 8 consecutive head dims of one token (Q, K) or 8 consecutive key positions of one head
+// dim (V^T).  Needs rows_per_batch % 32 == 0 (a sub-tile then lies inside one batch and one 32-key block) and
+// part_width % 32 == 0, head_dim % 8 == 0 (a 32-column group has one part, a 16-byte piece one head).
+template <int MT, int NT>
+__device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
+                                                            char* stg /* wave-private, NT * 2560 bytes */) {
+    constexpr int PITCH = 80, BLK = 32 * PITCH;
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int HW = p.rows_per_batch;
+    const int ppos = cfgpp_vt_pos(frow);                       // this lane's token -> key position inside its 32-block
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m0s = mw0 + i * 32;                          // first token row of the sub-tile (multiple of 32)
+        if (m0s >= p.M) continue;
+        const int b = m0s / HW, tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int ng = nw0 + j * 32;                       // first column of the 32-column group
+            const int part = (ng < p.N ? ng : p.N - 32) / p.part_width + p.part0;
+            char* blk = stg + j * BLK;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int n = ng + 8 * g + 4 * fhi;
+                n = n < p.N ? n : p.N - 4;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (part == 2 && !p.vt_linear) {               // transposed: [head dim column][key position]
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *reinterpret_cast<half_t*>(blk + (8 * g + 4 * fhi + k) * PITCH + ppos * 2) = (half_t)v[k];
+                } else if (part == 2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) *reinterpret_cast<half_t*>(blk + (8 * g + 4 * fhi + k) * PITCH + frow * 2) = (half_t)v[k];
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                    *reinterpret_cast<half4_t*>(blk + frow * PITCH + (8 * g + 4 * fhi) * 2) = o;
+                }
+            }
+        }
+        // 32 rows x 4 pieces of 16 B per 32-column group: 2 pieces per lane
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int ng = nw0 + j * 32;
+            if (ng >= p.N) continue;
+            const int part = ng / p.part_width + p.part0;
+            const char* blk = stg + j * BLK;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = lane + 64 * q;
+                const int r = c >> 2, c4 = c & 3;
+                const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * PITCH + c4 * 16);
+                if (part == 2) {                               // row r = head-dim column ng + r, piece = 8 key positions
+                    const int cn = (ng + r) % p.part_width;
+                    const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+                    const long bh = (long)b * p.heads + head;
+                    if (ng + r < p.N)
+                        *reinterpret_cast<half8_t*>(p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok0 + 8 * c4) = v;
+                } else {                                       // row r = token tok0 + r, piece = 8 head dims
+                    const int n = ng + 8 * c4;
+                    const int cn = n % p.part_width;
+                    const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+                    const long bh = (long)b * p.heads + head;
+                    half_t* base = part == 0 ? p.hq : p.hk;
+                    const int tp = part == 0 ? p.q_tok_pad : p.tok_pad;
+                    if (n < p.N)
+                        *reinterpret_cast<half8_t*>(base + (bh * tp + tok0 + r) * p.head_dim_pad + dd) = v;
+                }
+            }
+        }
+    }
+}
+
 // GLDS = true: tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 // AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
+// TPB = K-tiles per barrier (DMA path).  TPB = 2 with NST = 4 stages: the workgroup computes two 64-deep K-tiles
+// back to back between barriers while the DMA of the next PAIR is in flight (two tile times to land) - half the
+// barriers and start-of-tile LDS-read bubbles per FLOP, for the 4-wave tiles that run ONE workgroup per CU (one wave
+// per SIMD: nobody else covers those bubbles).
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int TPB = 1>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
     constexpr int NTHR = 64 * WM * WN;
+    static_assert(TPB == 1 || (TPB == 2 && NST == 4 && GLDS), "two tiles per barrier: 4-stage DMA ring");
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
@@ -299,13 +387,9 @@ igemm_kernel(const IGemmArgs p) {
     // the XCD's L2 while the - smaller - activation matrix is what every XCD streams): right for the weight-heavy
     // launches (GEGLU at M = 4096: 26 MB of weights vs 10 MB of activations; PMC showed 56 % L2 misses M-major).
     // The launcher picks by operand bytes (IGemmArgs::n_major); the result does not depend on it.
-    int tile_m, tile_n;
-    if (p.n_major && !is_tail) {
-        const int ntm = (p.M + BM - 1) / BM;
-        tile_n = wg / ntm; tile_m = wg - tile_n * ntm;
-    } else {
-        tile_m = wg / ntn; tile_n = wg - tile_m * ntn;
-    }
+    // (one division by a launcher-provided divisor: a two-sided branch here cost the 256 x 320 kernel 30 VGPRs -> spills)
+    const int wq = wg / p.walk_div, wr = wg - wq * p.walk_div;          // walk_div = ntn (M-major) or ntm (N-major)
+    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -453,22 +537,23 @@ igemm_kernel(const IGemmArgs p) {
         // are in flight / landed; a tile has NST-1 tile times to arrive (memory latency under load is of the
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
+        constexpr int NPRE = TPB == 1 ? NST - 1 : TPB;      // tiles in flight before the loop
 #pragma unroll
-        for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
-        if (NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
+        for (int s_ = 0; s_ < NPRE; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
+        if (TPB == 1 && NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        auto tile_body = [&](int kt, auto with_dma) {
+        // one K-tile: MFMAs on stage `cur`; DMA (if any) of tile `ktn` into stage `nxt`; wait + barrier if SYNC
+        auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma, auto with_sync) {
             constexpr bool DMA = decltype(with_dma)::value;
-            const int cur = (kt - kt_begin) % NST;
+            constexpr bool SYNC = decltype(with_sync)::value;
             const char* As = smem + cur * STAGE_BYTES;
             const char* Bs = As + BM * 128;
             // per-tile scalars of the NEXT tile's gather
             const half_t* src = p.a0; int cs = 0, Cs = p.C0, dpix = 0, dy = 0, dx = 0;
-            char* Asn = smem + ((kt - kt_begin + NST - 1) % NST) * STAGE_BYTES;
+            char* Asn = smem + nxt * STAGE_BYTES;
             char* Bsn = Asn + BM * 128;
             if constexpr (DMA) {
-                const int ktn = kt + NST - 1;
                 int tap = 0, cc = ktn << 6;
                 if (p.taps == 9) { const int cb = ktn / 9; tap = ktn - cb * 9; cc = cb << 6; }
                 const bool s0 = cc < p.C0;
@@ -494,7 +579,7 @@ igemm_kernel(const IGemmArgs p) {
                                                      (__attribute__((address_space(3))) void*)(Asn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
                 } else {
                     const int j = q - A_CH;
-                    const half_t* g = b_ptr[j] + ((long)(kt + NST - 1) << 6);
+                    const half_t* g = b_ptr[j] + ((long)ktn << 6);
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(Bsn + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
                 }
@@ -566,16 +651,44 @@ igemm_kernel(const IGemmArgs p) {
             if constexpr (DMA) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) if (q >= issued) piece(q);      // (none when SPAN <= NM)
-                // tile kt+1 has landed once at most the (NST-2) younger tiles' pieces are outstanding
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();
+            if constexpr (SYNC) {
+                if constexpr (TPB == 1 && NST == 2) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                } else {
+                    // the next tile(s) have landed once at most the younger tiles' pieces are outstanding.  More than one
+                    // tile in flight across the barrier: raw s_barrier (__syncthreads() would drain the DMA queue)
+                    if constexpr (TPB == 1 && DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
         };
-        int kt = kt_begin;
-        for (; kt + NST - 1 < kt_end; ++kt) tile_body(kt, std::true_type{});
-        for (; kt < kt_end; ++kt) tile_body(kt, std::false_type{});
+        if constexpr (TPB == 1) {
+            int kt = kt_begin;
+            for (; kt + NST - 1 < kt_end; ++kt)
+                tile_body(kt, (kt - kt_begin) % NST, kt + NST - 1, (kt - kt_begin + NST - 1) % NST, std::true_type{}, std::true_type{});
+            for (; kt < kt_end; ++kt) tile_body(kt, (kt - kt_begin) % NST, 0, 0, std::false_type{}, std::true_type{});
+        } else {
+            // pairs of tiles: stages {0,1} and {2,3} alternate; the pair after next streams in meanwhile
+            auto run = [&](int kt, int cur, int ktn, int nxt, bool dma, auto with_sync) {
+                if (dma) tile_body(kt, cur, ktn, nxt, std::true_type{}, with_sync);
+                else tile_body(kt, cur, 0, 0, std::false_type{}, with_sync);
+            };
+            int g = 0;
+            for (int kt = kt_begin; kt < kt_end; kt += 2, g ^= 1) {
+                const int s0 = g * 2, n0 = (g ^ 1) * 2;
+                if (kt + 1 < kt_end) {
+                    run(kt, s0, kt + 2, n0, kt + 2 < kt_end, std::false_type{});
+                    run(kt + 1, s0 + 1, kt + 3, n0 + 1, kt + 3 < kt_end, std::true_type{});
+                } else {
+                    run(kt, s0, kt + 2, n0, false, std::true_type{});
+                }
+            }
+        }
     } else {
         load_tile(kt_begin);
         store_tile(0);
@@ -661,6 +774,13 @@ igemm_kernel(const IGemmArgs p) {
             return;
         }
     }
+    // (not instantiated for the 10-accumulator-tile waves: it pushed the 256 x 320 kernel into scratch spills)
+    constexpr bool HEADS_FITS = WM * WN * NT * 2560 <= NST * STAGE_BYTES && MT * NT <= 8;
+    if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
+        (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
+        igemm_epilogue_heads_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560));
+        return;
+    }
     igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
 }
 
@@ -711,14 +831,14 @@ static int g_tail_split = 1;                        // 1 = K-split tiny grids wi
 static int g_n_major = -1;                          // tile walk: -1 = by operand bytes, 0 = always M-major, 1 = always N-major
 extern "C" void cfgpp_igemm_set_n_major(int mode) { g_n_major = mode; }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int TPB = 1>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
     constexpr int smem = NST * (BM + BN) * 128;
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST, TPB>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -745,6 +865,8 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
         }
     }
     const int n_tail = T - a.n_main;
+    if (n_tail > 0) a.n_major = 0;                     // K-split tiles keep the M-major numbering the reduce kernel uses
+    a.walk_div = a.n_major ? cdiv(a.M, BM) : cdiv(a.N, BN);
     hipLaunchKernelGGL(kern, dim3(a.n_main + n_tail * a.ksplit), dim3(NTHR), smem, stream, a);
     if (n_tail > 0)
         hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail, (WTM / 32) * (WTN / 32)), dim3(NTHR), 0, stream, a);
@@ -752,20 +874,20 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2, int TPB = 1>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
-        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST>(a, stream);
-        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST>(a, stream);
-        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST>(a, stream);
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST, TPB>(a, stream);
+        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST, TPB>(a, stream);
+        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST, TPB>(a, stream);
+        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST, TPB>(a, stream);
         default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
     }
 }
 
 }  // namespace
 
-// forced tile config for tests / tuning: 0 = heuristic; 1..3 tile shapes; +10 = register-staged
+// forced tile config for tests / tuning: 0 = heuristic; 1..11 tile shapes; +20 (21..23) = register-staged
 // variant of the same tile (the LDS-DMA variant is the default)
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
@@ -775,7 +897,7 @@ extern "C" void cfgpp_igemm_set_tail_split(int on) { g_tail_split = on ? 1 : 0; 
 
 static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
     bool glds = g_staging != 0;
-    if (cfg > 10) { cfg -= 10; glds = false; }
+    if (cfg > 20) { cfg -= 20; glds = false; }
     switch (cfg) {
         case 1: return glds ? launch_cfg<2, 2, 64, 64, true>(a, stream) : launch_cfg<2, 2, 64, 64, false>(a, stream);
         case 2: return glds ? launch_cfg<4, 1, 64, 64, true>(a, stream) : launch_cfg<4, 1, 64, 64, false>(a, stream);
@@ -793,6 +915,7 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
+        case 11: return launch_cfg<4, 1, 32, 160, true, 4, 2>(a, stream); // 128 x 160, 4 waves, TWO K-tiles per barrier (4-stage ring), one workgroup / CU
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -845,7 +968,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8 || h == 9) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     return launch_config(cfg, a, stream);

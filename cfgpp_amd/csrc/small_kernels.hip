@@ -78,7 +78,8 @@ conv_in_kernel(const TIN* __restrict__ z, half_t* __restrict__ out, const float*
 template <int CO, typename TOUT>
 __global__ void __launch_bounds__(256)
 conv_out_kernel(const half_t* __restrict__ x, TOUT* __restrict__ out, const half_t* __restrict__ w,
-                const float* __restrict__ bias, int R, int H, int W, int C, int cout_real) {
+                const float* __restrict__ bias, int R, int H, int W, int C, int cout_real,
+                float post_scale, float post_shift, int clamp01) {
     const int lane = threadIdx.x & 63;
     const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long total = (long)R * H * W;
@@ -111,6 +112,8 @@ conv_out_kernel(const half_t* __restrict__ x, TOUT* __restrict__ out, const half
 #pragma unroll
         for (int o = 0; o < CO; ++o) if (lane == o) v = acc[o];
         v += bias ? bias[lane] : 0.f;
+        v = v * post_scale + post_shift;                 // identity (1, 0), or the sampler's `img / 2 + 0.5`
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);      // `.clamp(0, 1)` (latent_diffusion.py:677)
         out[((long)(r * cout_real + lane) * H + y) * W + xq] = (TOUT)v;
     }
 }
@@ -276,8 +279,19 @@ int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, co
     return cfgpp_op_conv_in_ex(z, z_is_half, out, w, bias, R, zB, Cin, H, W, Cout, nullptr, nullptr, 1.0f, stream);
 }
 
+int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* w, const float* bias,
+                         int R, int H, int W, int C, int Cout, float post_scale, float post_shift, int clamp01, void* stream);
+
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                       int R, int H, int W, int C, int Cout, void* stream) {
+    return cfgpp_op_conv_out_ex(x, out, out_is_half, w, bias, R, H, W, C, Cout, 1.0f, 0.0f, 0, stream);
+}
+
+// out = conv3x3(x) * post_scale + post_shift, optionally clamped to [0, 1] (the VAE decoder's conv_out with the
+// sampler's image post-processing `(img / 2 + 0.5).clamp(0, 1)` folded in; v * 0.5 is exact, so the result is the
+// reference's two separate fp32 ops bit for bit)
+int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* w, const float* bias,
+                         int R, int H, int W, int C, int Cout, float post_scale, float post_shift, int clamp01, void* stream) {
     CFGPP_REQUIRE(Cout >= 1 && Cout <= 8 && C % 8 == 0, "conv_out: Cout=%d C=%d", Cout, C);
     CFGPP_REQUIRE(x && out && w, "conv_out: null pointer");
     const long total = (long)R * H * W;
@@ -285,11 +299,11 @@ int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, 
     hipStream_t s = (hipStream_t)stream;
     if (Cout > 4) {       // VAE encoder moments (8 channels); weights must hold 8 output rows
         CFGPP_REQUIRE(!out_is_half, "conv_out: 8-channel output is fp32 only");
-        hipLaunchKernelGGL((conv_out_kernel<8, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+        hipLaunchKernelGGL((conv_out_kernel<8, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
     } else if (out_is_half)
-        hipLaunchKernelGGL((conv_out_kernel<4, half_t>), grid, dim3(256), 0, s, (const half_t*)x, (half_t*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+        hipLaunchKernelGGL((conv_out_kernel<4, half_t>), grid, dim3(256), 0, s, (const half_t*)x, (half_t*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
     else
-        hipLaunchKernelGGL((conv_out_kernel<4, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout);
+        hipLaunchKernelGGL((conv_out_kernel<4, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,7 @@ struct cfgpp_vae : EngineBase {
     std::vector<Op> enc_plan;
     const void* in_img = nullptr; const float* in_noise = nullptr; float* out_z = nullptr; float* out_moments = nullptr;
     float* enc_co = nullptr;       // conv_out result [R][8][h][w] fp32
+    float post_scale = 1.0f, post_shift = 0.0f; int post_clamp = 0;     // folded into the decoder's conv_out (set per call)
     double dec_macs = 0, enc_macs = 0;
     half_t *tok_a = nullptr, *tok_o = nullptr, *hq = nullptr, *hk = nullptr, *hvt = nullptr, *smat = nullptr;
 };
@@ -284,7 +285,9 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
         half_t* dw = B.upload(r);
         cfgpp_vae* vv = v; half_t* gp = gn.p; const int HH = H, WW = W;
         v->macs_per_row += (double)H * W * 3 * 9.0 * Cc;
-        v->plan.push_back([=](hipStream_t s, int rows) { return cfgpp_op_conv_out(gp, vv->out_img, 0, dw, bo, rows, HH, WW, Cc, 3, s); });
+        v->plan.push_back([=](hipStream_t s, int rows) {
+            return cfgpp_op_conv_out_ex(gp, vv->out_img, 0, dw, bo, rows, HH, WW, Cc, 3, vv->post_scale, vv->post_shift, vv->post_clamp, s);
+        });
         v->tag(3, 0.0, "vae conv_out");
         v->rel(gn); v->rel(x);
     }
@@ -358,7 +361,21 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
 }
 
 // img[B][3][8h][8w] fp32 = decoder(post_quant_conv(z / scaling_factor)),  z [B][4][h][w] fp32
+static int vae_decode_impl(cfgpp_vae* v, const void* z, void* img, int B, void* stream);
+
 int cfgpp_vae_decode(cfgpp_vae* v, const void* z, void* img, int B, void* stream) {
+    if (v) { v->post_scale = 1.0f; v->post_shift = 0.0f; v->post_clamp = 0; }
+    return vae_decode_impl(v, z, img, B, stream);
+}
+
+// decode + the sampler's `(img / 2 + 0.5).clamp(0, 1)` (latent_diffusion.py:676-677, latent_sdxl.py:274-275) folded
+// into the last kernel: the image leaves the GPU ready for `.cpu()`
+int cfgpp_vae_decode_image(cfgpp_vae* v, const void* z, void* img, int B, void* stream) {
+    if (v) { v->post_scale = 0.5f; v->post_shift = 0.5f; v->post_clamp = 1; }
+    return vae_decode_impl(v, z, img, B, stream);
+}
+
+static int vae_decode_impl(cfgpp_vae* v, const void* z, void* img, int B, void* stream) {
     CFGPP_REQUIRE(v && v->finalized && z && img && B > 0 && B <= v->max_rows, "vae_decode: bad args (B=%d, max %d)", B, v ? v->max_rows : 0);
     v->in_z = z; v->out_img = img;
     if (v->tuned_rows != B && igemm_autotune_enabled()) { int e = v->tune_plan((hipStream_t)stream, B); if (e) return e; }

@@ -259,8 +259,11 @@ class StableDiffusion:
         if os.environ.get("CFGPP_TRACE"):
             torch.cuda.synchronize() if z.is_cuda else None
             print("[cfgpp] sampling loop done, decoding", file=sys.stderr, flush=True)
-        img = self.decode(z)
-        img = (img / 2 + 0.5).clamp(0, 1)
+        vae = self._get_vae()
+        if hasattr(vae, "decode_image"):        # HIP VAE: `/ 2 + 0.5` and the clamp are folded into its last kernel
+            img = vae.decode_image(z.to(self.work_device))
+        else:
+            img = (self.decode(z) / 2 + 0.5).clamp(0, 1)
         return img.detach().cpu()
 
     def _embeds(self, prompt, kwargs, n_cond=1):

@@ -160,7 +160,12 @@ class HipVAE:
             self.lib.cfgpp_vae_destroy(h)
             self._h = None
 
-    def decode(self, zt: torch.Tensor) -> torch.Tensor:
+    def decode_image(self, zt: torch.Tensor) -> torch.Tensor:
+        """zt -> ``(decode(zt) / 2 + 0.5).clamp(0, 1)`` with the post-processing of the solvers' ``sample()`` folded into
+        the decoder's last kernel (latent_diffusion.py:676-677)."""
+        return self.decode(zt, _entry="cfgpp_vae_decode_image")
+
+    def decode(self, zt: torch.Tensor, _entry: str = "cfgpp_vae_decode") -> torch.Tensor:
         """zt [B,4,h,w] -> image [B,3,8h,8w] fp32 on the GPU (reference: latent_diffusion.py:123-129)."""
         from ._lib import CfgppError, check
         z = zt.to(device=self.device, dtype=torch.float32).contiguous()
@@ -168,7 +173,7 @@ class HipVAE:
         if tuple(z.shape[1:]) != (4, self.h, self.w) or B > self.max_batch:
             raise CfgppError(f"HipVAE.decode: latent {tuple(z.shape)} does not fit engine [<= {self.max_batch}, 4, {self.h}, {self.w}]")
         img = torch.empty((B, 3, 8 * self.h, 8 * self.w), dtype=torch.float32, device=self.device)
-        check(self.lib.cfgpp_vae_decode(self._h, z.data_ptr(), img.data_ptr(), B, torch.cuda.current_stream().cuda_stream), "cfgpp_vae_decode")
+        check(getattr(self.lib, _entry)(self._h, z.data_ptr(), img.data_ptr(), B, torch.cuda.current_stream(self.device).cuda_stream), _entry)
         return img
 
     def encode(self, x, sample: bool = True, generator=None, noise=None, return_moments: bool = False):

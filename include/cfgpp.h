@@ -148,6 +148,9 @@ void cfgpp_vae_destroy(cfgpp_vae* v);
 int cfgpp_vae_load_tensor(cfgpp_vae* v, const char* key, const void* host, int dtype, const long* shape, int ndim);
 int cfgpp_vae_finalize(cfgpp_vae* v);
 int cfgpp_vae_decode(cfgpp_vae* v, const void* z, void* img, int B, void* stream);
+/* decode + `(img / 2 + 0.5).clamp(0, 1)` of the solvers' sample() (latent_diffusion.py:676-677,
+ * latent_sdxl.py:274-275) in the decoder's last kernel: img[B][3][8h][8w] fp32 in [0, 1]. */
+int cfgpp_vae_decode_image(cfgpp_vae* v, const void* z, void* img, int B, void* stream);
 /* Encoder (replaces `self.vae.encode(x).latent_dist.sample() * scale`, latent_diffusion.py:117-121,
  * latent_sdxl.py:150-153); available when every encoder.* and quant_conv.* tensor was loaded.
  * img [B][3][8h][8w] f32, noise [B][4][h][w] f32 or NULL (posterior mean), z [B][4][h][w] f32,
@@ -188,6 +191,10 @@ int cfgpp_op_vae_posterior(const float* conv_out, const float* qw, const float* 
                            float* moments, int B, int HW, float scale, void* stream);
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                       int R, int H, int W, int C, int Cout, void* stream);
+/* the same with `* post_scale + post_shift` and an optional clamp to [0, 1] applied to the fp32 result (the VAE
+ * decoder's conv_out with the sampler's `(img / 2 + 0.5).clamp(0, 1)` folded in) */
+int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* w, const float* bias,
+                         int R, int H, int W, int C, int Cout, float post_scale, float post_shift, int clamp01, void* stream);
 int cfgpp_op_sinusoid(const float* vals, float scalar, float* out, int count, int dim, int out_ld, int out_off,
                       void* stream);
 int cfgpp_op_skinny_gemm(const float* x, int ldx, const void* w, const float* bias, const float* addend, int add_ld,

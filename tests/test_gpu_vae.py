@@ -22,6 +22,8 @@ def test_vae_decode_vs_cpu_reference(hw, B):
     assert img.shape == ref.shape == (B, 3, 8 * hw[0], 8 * hw[1])
     rel = float((img - ref).norm() / ref.norm())
     assert torch.isfinite(img).all() and rel < 1e-2, f"VAE decode rel-L2 {rel:.3e}"
+    # the folded image post-processing of sample(): bit-identical to the reference's two fp32 ops on the decoded image
+    assert torch.equal(hip.decode_image(z.cuda()).cpu(), (img / 2 + 0.5).clamp(0, 1))
 
 
 @pytest.mark.parametrize("hw,B", [((16, 16), 2), ((16, 32), 1)])
