@@ -281,7 +281,7 @@ attn_kernel(const AttnArgs a) {
 // K tile  : LDS [64 keys  ][64 halfs], row = key,   16-B chunk c = 8 head dims
 // V^T tile: LDS [64 d-rows][64 keys ], row = d,     16-B chunk c = 8 (permuted) keys
 // physical chunk = logical chunk ^ ((row >> 1) & 7); one DMA piece = 8 rows x 128 B = 64 lanes x 16 B.
-template <int D16, bool ONES, int NST>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU; 2: 32 KB, 4 / CU)
+template <int D16, bool ONES, int NST>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU)
 __global__ void __launch_bounds__(256)
 attn64_kernel(const AttnArgs a) {
     constexpr int DP = 64, DT = 2;
@@ -355,6 +355,7 @@ attn64_kernel(const AttnArgs a) {
         if (NST > 2 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");           // (the barrier intrinsic alone does not order the LDS reads below)
         if (t + NST - 1 < ntiles) dma_tile(t + NST - 1, (t + NST - 1) % NST);
         const char* Ks = smem + (t % NST) * STAGE;
         const char* Vs = Ks + TILE;
@@ -503,7 +504,7 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel on a 3-stage ring, 2 = 2-stage ring, 0 = register-staged kernel (A/B switch)
+static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch)
 
 extern "C" {
 
@@ -541,14 +542,9 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     const int d16 = (d + 15) / 16, dt = (d + 31) / 32;
     const bool ones = (d % 32) != 0;
     if (dt == 2 && g_attn_dma) {                   // dp = 64 (d = 40, 48, 56, 64): LDS-DMA kernel
-        int rc;
-        if (g_attn_dma == 2) {
-            if (d16 == 3) rc = launch_attn64<3, true, 2>(a, grid, s);
-            else rc = ones ? launch_attn64<4, true, 2>(a, grid, s) : launch_attn64<4, false, 2>(a, grid, s);
-        } else {
-            if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
-            else rc = ones ? launch_attn64<4, true, 3>(a, grid, s) : launch_attn64<4, false, 3>(a, grid, s);
-        }
+        int rc;        // (a 2-stage ring was measured within 1 % of the 3-stage one and is not built)
+        if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
+        else rc = ones ? launch_attn64<4, true, 3>(a, grid, s) : launch_attn64<4, false, 3>(a, grid, s);
         if (rc) return -1;
         CFGPP_HIP_CHECK(hipGetLastError());
         return 0;

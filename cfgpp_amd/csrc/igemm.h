@@ -46,7 +46,7 @@ struct IGemmArgs {
     int n_main;               // tiles [0, n_main) are computed whole by one block each
     int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
     float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
-    int cfg_hint;             // 0 = heuristic; 1, 4 .. 11 = tile config pinned by the engine's in-situ tuning pass
+    int cfg_hint;             // 0 = heuristic; 1, 4 .. 8, 10 = tile config pinned by the engine's in-situ tuning pass
     int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
     int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
     int n_major;              // 1: N-major tile walk (weight slabs stay L2-resident): weight-heavy launches

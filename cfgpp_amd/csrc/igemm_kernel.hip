@@ -345,15 +345,10 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 // AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
-// TPB = K-tiles per barrier (DMA path).  TPB = 2 with NST = 4 stages: the workgroup computes two 64-deep K-tiles
-// back to back between barriers while the DMA of the next PAIR is in flight (two tile times to land) - half the
-// barriers and start-of-tile LDS-read bubbles per FLOP, for the 4-wave tiles that run ONE workgroup per CU (one wave
-// per SIMD: nobody else covers those bubbles).
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int TPB = 1>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
     constexpr int NTHR = 64 * WM * WN;
-    static_assert(TPB == 1 || (TPB == 2 && NST == 4 && GLDS), "two tiles per barrier: 4-stage DMA ring");
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int RSTEP = NTHR / 8;            // rows covered per loader pass
@@ -537,16 +532,14 @@ igemm_kernel(const IGemmArgs p) {
         // are in flight / landed; a tile has NST-1 tile times to arrive (memory latency under load is of the
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
-        constexpr int NPRE = TPB == 1 ? NST - 1 : TPB;      // tiles in flight before the loop
 #pragma unroll
-        for (int s_ = 0; s_ < NPRE; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
-        if (TPB == 1 && NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
+        for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
+        if (NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // one K-tile: MFMAs on stage `cur`; DMA (if any) of tile `ktn` into stage `nxt`; wait + barrier if SYNC
-        auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma, auto with_sync) {
+        // one K-tile: MFMAs on stage `cur`; DMA (if any) of tile `ktn` into stage `nxt`; wait + barrier
+        auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma) {
             constexpr bool DMA = decltype(with_dma)::value;
-            constexpr bool SYNC = decltype(with_sync)::value;
             const char* As = smem + cur * STAGE_BYTES;
             const char* Bs = As + BM * 128;
             // per-tile scalars of the NEXT tile's gather
@@ -652,43 +645,23 @@ igemm_kernel(const IGemmArgs p) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) if (q >= issued) piece(q);      // (none when SPAN <= NM)
             }
-            if constexpr (SYNC) {
-                if constexpr (TPB == 1 && NST == 2) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                } else {
-                    // the next tile(s) have landed once at most the younger tiles' pieces are outstanding.  More than one
-                    // tile in flight across the barrier: raw s_barrier (__syncthreads() would drain the DMA queue)
-                    if constexpr (TPB == 1 && DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
+            if constexpr (NST == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            } else {
+                // the next tile has landed once at most the younger tiles' pieces are outstanding.  More than one tile
+                // in flight across the barrier: raw s_barrier (__syncthreads() would drain the DMA queue)
+                if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
         };
-        if constexpr (TPB == 1) {
-            int kt = kt_begin;
-            for (; kt + NST - 1 < kt_end; ++kt)
-                tile_body(kt, (kt - kt_begin) % NST, kt + NST - 1, (kt - kt_begin + NST - 1) % NST, std::true_type{}, std::true_type{});
-            for (; kt < kt_end; ++kt) tile_body(kt, (kt - kt_begin) % NST, 0, 0, std::false_type{}, std::true_type{});
-        } else {
-            // pairs of tiles: stages {0,1} and {2,3} alternate; the pair after next streams in meanwhile
-            auto run = [&](int kt, int cur, int ktn, int nxt, bool dma, auto with_sync) {
-                if (dma) tile_body(kt, cur, ktn, nxt, std::true_type{}, with_sync);
-                else tile_body(kt, cur, 0, 0, std::false_type{}, with_sync);
-            };
-            int g = 0;
-            for (int kt = kt_begin; kt < kt_end; kt += 2, g ^= 1) {
-                const int s0 = g * 2, n0 = (g ^ 1) * 2;
-                if (kt + 1 < kt_end) {
-                    run(kt, s0, kt + 2, n0, kt + 2 < kt_end, std::false_type{});
-                    run(kt + 1, s0 + 1, kt + 3, n0 + 1, kt + 3 < kt_end, std::true_type{});
-                } else {
-                    run(kt, s0, kt + 2, n0, false, std::true_type{});
-                }
-            }
-        }
+        int kt = kt_begin;
+        for (; kt + NST - 1 < kt_end; ++kt)
+            tile_body(kt, (kt - kt_begin) % NST, kt + NST - 1, (kt - kt_begin + NST - 1) % NST, std::true_type{});
+        for (; kt < kt_end; ++kt) tile_body(kt, (kt - kt_begin) % NST, 0, 0, std::false_type{});
     } else {
         load_tile(kt_begin);
         store_tile(0);
@@ -831,14 +804,14 @@ static int g_tail_split = 1;                        // 1 = K-split tiny grids wi
 static int g_n_major = -1;                          // tile walk: -1 = by operand bytes, 0 = always M-major, 1 = always N-major
 extern "C" void cfgpp_igemm_set_n_major(int mode) { g_n_major = mode; }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, int TPB = 1>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
     constexpr int smem = NST * (BM + BN) * 128;
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST, TPB>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -874,20 +847,20 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2, int TPB = 1>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST, TPB>(a, stream);
-        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST, TPB>(a, stream);
-        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST, TPB>(a, stream);
-        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST, TPB>(a, stream);
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
+        case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST>(a, stream);
+        case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST>(a, stream);
+        case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST>(a, stream);
         default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
     }
 }
 
 }  // namespace
 
-// forced tile config for tests / tuning: 0 = heuristic; 1..11 tile shapes; +20 (21..23) = register-staged
+// forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
 // variant of the same tile (the LDS-DMA variant is the default)
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
@@ -910,12 +883,12 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // at M = 4096, N = 1280 and 128 x 320 at M = 16384, N = 640)
         case 7: return launch_cfg<4, 1, 32, 160, true>(a, stream);     // 128 x 160, 4 waves, 2 workgroups / CU
         case 8: return launch_cfg<4, 2, 32, 160, true>(a, stream);     // 128 x 320, 8 waves
-        case 9: return launch_cfg<4, 1, 32, 160, true, 3>(a, stream);  // 128 x 160, 4 waves, 3-stage ring, ONE workgroup / CU (256-tile grids)
+        // (measured and dropped: the 128 x 160 tile on a 3-stage ring with a raw s_barrier - +-1 % - and with two K-tiles
+        //  per barrier on a 4-stage ring - 9 .. 30 % slower: the single-workgroup-per-CU case is not barrier-bound)
         // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
-        case 11: return launch_cfg<4, 1, 32, 160, true, 4, 2>(a, stream); // 128 x 160, 4 waves, TWO K-tiles per barrier (4-stage ring), one workgroup / CU
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -968,7 +941,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     return launch_config(cfg, a, stream);

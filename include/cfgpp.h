@@ -181,8 +181,7 @@ int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* 
 int cfgpp_op_attention_prepare_vt(void* vt, int BH, int d, int tok_pad, void* stream);
 int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, int B, int heads, int d,
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
-/* A/B switch for head dims padded to 64: 1 (default) LDS-DMA kernel on a 3-stage ring, 2 the same on a 2-stage
- * ring, 0 the register-staged kernel */
+/* A/B switch for head dims padded to 64: 1 (default) the LDS-DMA kernel, 0 the register-staged kernel */
 void cfgpp_attention_set_dma(int mode);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                      int R, int zB, int Cin, int H, int W, int Cout, void* stream);

@@ -15,7 +15,7 @@ SHAPES = [  # name, kind, batch rows, HW side, Cin, Cout(N)
     ("lin_l2_1280", "lin", 16, 16, 1280, 1280), ("lin_l2_ffout", "lin", 16, 16, 5120, 1280), ("lin_l2_qkv", "lin", 16, 16, 1280, 3840),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,4,5,6,7,8,9,11").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,4,5,6,7,8,10").split(",")]
 iters = int(os.environ.get("ITERS", "20"))
 def timeit(fn):
     for _ in range(3): fn()
