@@ -89,7 +89,11 @@ PROTOTYPES = {
     "cfgpp_igemm_set_tail_split": (None, [_I]),
     "cfgpp_igemm_set_autotune": (None, [_I]),
     "cfgpp_igemm_set_n_major": (None, [_I]),
+    "cfgpp_igemm_force_split": (None, [_I]),
+    "cfgpp_igemm_set_big_split": (None, [_I]),
+    "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
     "cfgpp_groupnorm_set_mode": (None, [_I]),
+    "cfgpp_layernorm_set_rows_per_wave": (None, [_I]),
     "cfgpp_attention_set_dma": (None, [_I]),
 }
 

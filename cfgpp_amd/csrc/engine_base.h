@@ -74,20 +74,20 @@ struct EngineBase {
             tuned_rows = rows;
             return 0;
         }
-        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 10};
+        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14};
         const size_t n = plan.size();
         plan_hint.resize(n, nullptr);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;
         std::vector<hipEvent_t> ev(n + 1, nullptr);
         for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1;
-        std::vector<float> base(n, 1e30f), best(n, 1e30f);
+        std::vector<float> base(n, 1e30f), best(n, 1e30f), t(n);
         std::vector<int> bestc(n, 0);
         int rc = 0;
-        for (int c : cands) {
-            std::vector<float> t(n, 1e30f);
+        // two timed forwards with the hints as they stand; t[i] = the faster of the two for every hinted launch
+        auto timed_passes = [&]() {
+            std::fill(t.begin(), t.end(), 1e30f);
             for (int rep = 0; rep < 2 && rc == 0; ++rep) {
-                for (int& h : cfg_hints) h = c;
                 if (hipEventRecord(ev[0], s) != hipSuccess) rc = -1;
                 for (size_t i = 0; i < n && rc == 0; ++i) { rc = plan[i](s, rows); if (rc == 0 && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = -1; }
                 if (rc == 0 && hipEventSynchronize(ev[n]) != hipSuccess) rc = -1;
@@ -97,14 +97,29 @@ struct EngineBase {
                     if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess && ms < t[i]) t[i] = ms;
                 }
             }
+        };
+        const unsigned mask = igemm_tune_mask();
+        for (int c : cands) {
+            if (c != 0 && !((mask >> c) & 1u)) continue;
+            for (int& h : cfg_hints) h = c;
+            timed_passes();
             for (size_t i = 0; i < n; ++i) {
                 if (c == 0) base[i] = t[i];
                 if (t[i] < best[i]) { best[i] = t[i]; bestc[i] = c; }
             }
         }
-        for (int& h : cfg_hints) h = 0;
         for (size_t i = 0; i < n; ++i)
-            if (plan_hint[i] && bestc[i] != 0 && best[i] < 0.97f * base[i]) *plan_hint[i] = bestc[i];
+            if (plan_hint[i] && !(bestc[i] != 0 && best[i] < 0.97f * base[i])) { bestc[i] = 0; best[i] = base[i]; }
+        // second stage: with the tile pinned, the tile walk (M-major / N-major; the default is a rule on operand bytes).
+        // Every launch runs with its own pinned tile, so the cache state each one sees is the final plan's.
+        for (int walk = 1; walk <= 2 && rc == 0 && (mask >> 31); ++walk) {
+            for (size_t i = 0; i < n; ++i) if (plan_hint[i]) *plan_hint[i] = (bestc[i] & 63) | (walk << 6);
+            timed_passes();
+            for (size_t i = 0; i < n; ++i)
+                if (plan_hint[i] && t[i] < 0.97f * best[i]) { best[i] = t[i]; bestc[i] = (bestc[i] & 63) | (walk << 6); }
+        }
+        for (int& h : cfg_hints) h = 0;
+        for (size_t i = 0; i < n; ++i) if (plan_hint[i]) *plan_hint[i] = bestc[i];
         for (auto& e : ev) hipEventDestroy(e);
         if (rc == 0) tuned_by_rows[rows] = std::vector<int>(cfg_hints.begin(), cfg_hints.end());
         tuned_rows = rows;

@@ -46,12 +46,16 @@ struct IGemmArgs {
     int n_main;               // tiles [0, n_main) are computed whole by one block each
     int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
     float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
-    int cfg_hint;             // 0 = heuristic; 1, 4 .. 8, 10 = tile config pinned by the engine's in-situ tuning pass
+    int cfg_hint;             // pinned by the engine's in-situ tuning pass: bits 0-5 tile config (0 = heuristic; 1, 4 .. 12, 14),
+                              // bits 6-7 tile walk (0 = by operand bytes, 1 = M-major, 2 = N-major)
     int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
     int staged_epi;           // 1: EPI_STORE goes through the LDS-transposed, row-coalesced epilogue
     int n_major;              // 1: N-major tile walk (weight slabs stay L2-resident): weight-heavy launches
     int walk_div;             // tiles along the minor axis of the walk (filled by igemm_launch)
+    int walk_hint;            // decoded from cfg_hint by igemm_launch
+    int split;                // >= 2: K-split every tile this many ways (igemm_launch's big-tile rule / diagnostics); 0: launcher's rule
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);
 int igemm_autotune_enabled();
+unsigned igemm_tune_mask();

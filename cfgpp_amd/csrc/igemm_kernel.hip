@@ -373,7 +373,12 @@ igemm_kernel(const IGemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     } else {
-        const int b2 = bid - p.n_main;
+        // same XCD-contiguous numbering over the (tile, k-slice) pairs: the k-slices of neighbouring tiles (which share
+        // activation rows / weight slabs slice by slice) meet in one XCD's L2
+        const int b1 = bid - p.n_main, nb = (int)gridDim.x - p.n_main;
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = b1 & 7, idx = b1 >> 3;
+        const int b2 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         wg = p.n_main + b2 / p.ksplit;
         ksl = b2 - (b2 / p.ksplit) * p.ksplit;
     }
@@ -534,7 +539,7 @@ igemm_kernel(const IGemmArgs p) {
         const int nk = kt_end - kt_begin;
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
-        if (NST > 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");
+        if (NST > 2 && nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");   // NST-1 tiles issued: the oldest has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // one K-tile: MFMAs on stage `cur`; DMA (if any) of tile `ktn` into stage `nxt`; wait + barrier
@@ -726,7 +731,7 @@ igemm_kernel(const IGemmArgs p) {
     const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
     if (is_tail) {
         // fp32 partial, register order, coalesced: ws[((block * REGS + r) * NTHR) + tid]
-        float* ws = p.ws + (long)(bid - p.n_main) * (MT * NT * 16) * NTHR + tid;
+        float* ws = p.ws + ((long)(wg - p.n_main) * p.ksplit + ksl) * (MT * NT * 16) * NTHR + tid;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -795,7 +800,7 @@ igemm_reduce_kernel(const IGemmArgs p) {
 
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
-constexpr long WS_MAX_PARTS = 2048;                 // partial tiles (64 KiB each) -> 128 MiB
+constexpr long WS_BYTES = 128L << 20;               // fp32 partials of one launch: T * S * BM * BN * 4 bytes must fit
 static int g_staged_epi = 1;
 extern "C" void cfgpp_igemm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 : 0; }
 static int g_big_tiles = 1;
@@ -824,16 +829,22 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     {   // weight bytes vs unique activation bytes (a 3x3 conv re-reads each pixel through L2: its A operand is M x Cin)
         const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
         a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && cdiv(a.N, BN) >= 8)) ? 1 : 0;
+        if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     }
-    // K-split only for tiny grids with a long K (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040):
-    // every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
-    // finishes them.  S is chosen so that T*S fills the resident slots once or twice.
-    if (g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
-        int S = (slots + T - 1) / T;                       // one full round
-        if (KT / S < 12) S = KT / 12;
-        if (S > 16) S = 16;
-        if (S >= 2 && (long)T * S <= WS_MAX_PARTS) {
-            if (!g_ws && hipMalloc((void**)&g_ws, (size_t)WS_MAX_PARTS * 64 * 1024) != hipSuccess) g_ws = nullptr;
+    // K-split: every tile is split S ways into fp32 partials (coalesced, register order) and igemm_reduce_kernel
+    // finishes them.  (a) igemm_launch's big-tile rule / diagnostics pass S in IGemmArgs::split; (b) tiny grids with a
+    // long K on the 64x64-wave tiles (the 8x8-level convs: 80 tiles on 256 CUs, K = 11520..23040): S is chosen so
+    // that T*S fills the resident slots once or twice.
+    {
+        int S = 0;
+        if (a_in.split >= 2 && a.epi == EPI_STORE) S = a_in.split < KT ? a_in.split : KT;
+        else if (g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
+            S = (slots + T - 1) / T;                       // one full round
+            if (KT / S < 12) S = KT / 12;
+            if (S > 16) S = 16;
+        }
+        if (S >= 2 && (long)T * S * BM * BN * 4 <= WS_BYTES) {
+            if (!g_ws && hipMalloc((void**)&g_ws, (size_t)WS_BYTES) != hipSuccess) g_ws = nullptr;
             if (g_ws) { a.n_main = 0; a.ksplit = S; a.ws = g_ws; }
         }
     }
@@ -883,8 +894,15 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // at M = 4096, N = 1280 and 128 x 320 at M = 16384, N = 640)
         case 7: return launch_cfg<4, 1, 32, 160, true>(a, stream);     // 128 x 160, 4 waves, 2 workgroups / CU
         case 8: return launch_cfg<4, 2, 32, 160, true>(a, stream);     // 128 x 320, 8 waves
-        // (measured and dropped: the 128 x 160 tile on a 3-stage ring with a raw s_barrier - +-1 % - and with two K-tiles
-        //  per barrier on a 4-stage ring - 9 .. 30 % slower: the single-workgroup-per-CU case is not barrier-bound)
+        // Deeper LDS rings of the small tiles (3 / 4 stages, counted vmcnt + raw s_barrier): with the operands hot in L2 they
+        // are +-1 % of the 2-stage form (profiles/r02/ab/igemm_ring_variants_run5.txt), but inside a forward every launch
+        // streams its weights from HBM / the Infinity Cache, where one tile of lookahead (640 MFMA cycles on a 4-wave tile)
+        // is shorter than the miss latency.  Only the in-situ tuner picks them (same K order: bit-identical results).
+        // (two K-tiles per barrier on a 4-stage ring was 9 .. 30 % slower and stays dropped)
+        case 9: return launch_cfg<4, 1, 32, 160, true, 3>(a, stream);  // 128 x 160, 3 stages (110 KB, 1 workgroup / CU)
+        case 11: return launch_cfg<4, 1, 32, 160, true, 4>(a, stream); // 128 x 160, 4 stages (147 KB)
+        case 12: return launch_cfg<2, 2, 64, 64, true, 3>(a, stream);  // 128 x 128, 3 stages (96 KB)
+        case 14: return launch_cfg<4, 2, 64, 64, true, 3>(a, stream);  // 256 x 128, 3 stages (144 KB)
         // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
@@ -900,7 +918,14 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
 // not depend on the choice (bit-identical); K-split launches (different summation order) stay rule-based.
 static int g_autotune = 1;
 extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
+static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
+extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
+static int g_big_split_min_kt = 32;    // big-tile K-split rule: least K-tiles per slice (0 = rule off)
+extern "C" void cfgpp_igemm_set_big_split(int min_kt) { g_big_split_min_kt = min_kt > 0 ? min_kt : 0; }
 int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_staging != 0; }
+static unsigned g_tune_mask = 0xffffffffu;   // bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs
+extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
+unsigned igemm_tune_mask() { return g_tune_mask; }
 
 int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
@@ -936,13 +961,31 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         else cfg = 3;
         if (a.epi == EPI_GEGLU && cfg == 3) cfg = 1;   // GEGLU needs 64-wide wave tiles
     }
-    if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0) {
+    // Big-tile K-split (rule-based like the 8x8-level split, so the result never depends on tuning): M x N is too small
+    // for the 8-wave tiles to fill 256 CUs (M = 4096, N = 1280: 128 tiles of 128 x 320, and the 4-wave 128 x 160 tile
+    // that does fill them runs one wave per SIMD at 600-650 TF/s) but K is long (the 16x16-level convs, K = 5760 .. 23040,
+    // and the feed-forward output projection, K = 5120): 128 x 320 tiles, each split 256 / T ways.
+    bool big_split = false;
+    a.split = 0;
+    if (g_force_cfg != 0) a.split = g_force_split;
+    else if (g_big_split_min_kt > 0 && g_big_tiles && g_staging != 0 && g_tail_split && a.epi == EPI_STORE && a.N % 320 == 0) {
+        const long t8 = (long)cdiv(a.M, 128) * (a.N / 320);
+        const int KT = a.K >> 6;
+        if (t8 >= 64 && t8 <= 128) {
+            int S = (int)(256 / t8);
+            while (S >= 2 && KT / S < g_big_split_min_kt) --S;
+            if (S >= 2 && t8 * S >= 192) { cfg = 8; a.split = S; big_split = true; }
+        }
+    }
+    if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0 && !big_split) {
         const int KT = a.K >> 6;
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
-        const int h = a.cfg_hint;
-        const bool valid = (h == 1 || h == 4 || h == 6 || (h == 10 && a.epi == EPI_GEGLU) || ((h == 5 || h == 7 || h == 8) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+        const int h = a.cfg_hint & 63;
+        const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
+                            ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
+    a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)
     return launch_config(cfg, a, stream);
 }

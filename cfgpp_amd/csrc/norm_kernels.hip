@@ -350,64 +350,82 @@ gn_apply_kernel(GNArgs a) {
 }
 
 int g_gn_mode = 0;        // 0 = auto, 1 = always the two-launch form, 2 = slab kernel whenever the slab fits
+int g_ln_rpw = 0;         // LayerNorm rows per wave: 0 = by row count, 1 / 2 / 4 forced (diagnostics)
 
 template <int MAXCH, int NT>
 void launch_gn_slab(const GNArgs& a, int wgs, hipStream_t s) {
     hipLaunchKernelGGL((gn_slab_kernel<MAXCH, NT>), dim3(wgs), dim3(NT), 0, s, a);
 }
 
-// ---- LayerNorm: one wave per token row, row held in registers ----------------
-template <int MAXV>   // MAXV = max half4 chunks per lane (C <= 64*4*MAXV)
+// ---- LayerNorm: RPW token rows per wave, rows held in registers ----------------
+// One row is only 640 B .. 2.5 KB: with one row per wave the kernel is latency- not bandwidth-bound (a CU has
+// 32 waves x 640 B = 20 KB in flight, the HBM pipe wants ~64 KB per CU).  Each wave therefore loads RPW rows before it
+// reduces any of them; the per-row arithmetic (8-byte chunks lane + 64 j, butterfly sums, exact two-pass variance) is
+// the same for every RPW, so the result does not depend on it.
+template <int MAXV, int RPW>   // MAXV = max half4 chunks per lane (C <= 64*4*MAXV)
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
                  const float* __restrict__ beta, long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
     const int chunks = C / 4;
-    const half_t* xr = x + row * C;
-    float v[MAXV][4];
-    float sum = 0.f;
+    float v[RPW][MAXV][4];
+    float sum[RPW];
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int ch = lane + j * 64;
-        if (ch < chunks) {
-            const half4_t h = *reinterpret_cast<const half4_t*>(xr + ch * 4);
+    for (int r = 0; r < RPW; ++r) {
+        const long row = row0 + r < rows ? row0 + r : rows - 1;      // clamp: the tail rows are computed twice, stored once
+        const half_t* xr = x + row * C;
+        sum[r] = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { v[j][k] = (float)h[k]; sum += v[j][k]; }
-        } else {
+        for (int j = 0; j < MAXV; ++j) {
+            const int ch = lane + j * 64;
+            if (ch < chunks) {
+                const half4_t h = *reinterpret_cast<const half4_t*>(xr + ch * 4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[j][k] = 0.f;
+                for (int k = 0; k < 4; ++k) { v[r][j][k] = (float)h[k]; sum[r] += v[r][j][k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[r][j][k] = 0.f;
+            }
         }
     }
+    float mean[RPW], rstd[RPW];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
+    for (int r = 0; r < RPW; ++r) {
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int ch = lane + j * 64;
-        if (ch < chunks) {
+        for (int o = 32; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o);
+        mean[r] = sum[r] / (float)C;
+        float sq = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = v[j][k] - mean; sq += d * d; }
+        for (int j = 0; j < MAXV; ++j) {
+            const int ch = lane + j * 64;
+            if (ch < chunks) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = v[r][j][k] - mean[r]; sq += d * d; }
+            }
         }
-    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = rsqrtf(sq / (float)C + eps);
-    half_t* yr = y + row * C;
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        rstd[r] = rsqrtf(sq / (float)C + eps);
+    }
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         const int ch = lane + j * 64;
         if (ch < chunks) {
             const float4 g = *reinterpret_cast<const float4*>(gamma + ch * 4);
             const float4 b = *reinterpret_cast<const float4*>(beta + ch * 4);
-            half4_t o;
-            o[0] = (half_t)((v[j][0] - mean) * rstd * g.x + b.x);
-            o[1] = (half_t)((v[j][1] - mean) * rstd * g.y + b.y);
-            o[2] = (half_t)((v[j][2] - mean) * rstd * g.z + b.z);
-            o[3] = (half_t)((v[j][3] - mean) * rstd * g.w + b.w);
-            *reinterpret_cast<half4_t*>(yr + ch * 4) = o;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                if (row0 + r < rows) {
+                    half4_t o;
+                    o[0] = (half_t)((v[r][j][0] - mean[r]) * rstd[r] * g.x + b.x);
+                    o[1] = (half_t)((v[r][j][1] - mean[r]) * rstd[r] * g.y + b.y);
+                    o[2] = (half_t)((v[r][j][2] - mean[r]) * rstd[r] * g.z + b.z);
+                    o[3] = (half_t)((v[r][j][3] - mean[r]) * rstd[r] * g.w + b.w);
+                    *reinterpret_cast<half4_t*>(y + (row0 + r) * C + ch * 4) = o;
+                }
+            }
         }
     }
 }
@@ -481,6 +499,7 @@ int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream) {
 // (src1 may be NULL / C1 = 0).  stats: device scratch of N * (1024*G*2 + G*2) floats (the two-launch form uses
 // the first N * 64 * G * 2 of them).
 void cfgpp_groupnorm_set_mode(int mode) { g_gn_mode = mode; }
+void cfgpp_layernorm_set_rows_per_wave(int rpw) { g_ln_rpw = (rpw == 1 || rpw == 2 || rpw == 4) ? rpw : 0; }
 
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
@@ -555,14 +574,17 @@ int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* 
     CFGPP_REQUIRE(C % 4 == 0 && C <= 64 * 4 * 8, "layernorm: C=%d must be a multiple of 4 and <= 2048", C);
     CFGPP_REQUIRE(x && y && gamma && beta && rows > 0, "layernorm: bad args");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cdiv(rows, 4));
     const int need = cdiv(C / 4, 64);
-    if (need <= 2)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps);
-    else if (need <= 5)
-        hipLaunchKernelGGL(layernorm_kernel<5>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps);
+    // rows per wave: as many (4 / 2 / 1) as still leave >= 16 waves per CU on the 256 CUs
+    const int rpw = g_ln_rpw > 0 ? g_ln_rpw : (rows >= 4L * 4096 ? 4 : rows >= 2L * 4096 ? 2 : 1);
+#define LN_LAUNCH(MV, RP) hipLaunchKernelGGL((layernorm_kernel<MV, RP>), dim3(cdiv(rows, 4 * RP)), dim3(256), 0, s, \
+                                             (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps)
+#define LN_BY_RPW(MV) do { if (rpw >= 4) LN_LAUNCH(MV, 4); else if (rpw == 2) LN_LAUNCH(MV, 2); else LN_LAUNCH(MV, 1); } while (0)
+    if (need <= 2) LN_BY_RPW(2);
+    else if (need <= 5) LN_BY_RPW(5);
+    else LN_BY_RPW(8);
+#undef LN_BY_RPW
+#undef LN_LAUNCH
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

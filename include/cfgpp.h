@@ -174,6 +174,9 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
 void cfgpp_groupnorm_set_mode(int mode);
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream);
+/* development / A-B switch: token rows each wave of the LayerNorm kernel keeps in flight (0 = by row count, 1 / 2 / 4);
+ * the result does not depend on it. */
+void cfgpp_layernorm_set_rows_per_wave(int rpw);
 /* V^T contract of cfgpp_op_attention: vt is [B*heads][dp][tok_pad] with the keys of every 32-key block
  * permuted - key k lives in column (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1) (bits 2 and 3 swapped), which is
  * how the QKV projection (cfgpp_op_igemm_heads) writes it; and when d % 32 != 0, row d of every matrix holds
@@ -213,11 +216,21 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
-void cfgpp_igemm_force_config(int cfg);   /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128; 11..13 = register-staged 1..3 */
-void cfgpp_igemm_set_tail_split(int on);
-/* tile walk of the implicit GEMM: -1 (default) by operand bytes, 0 always M-major, 1 always N-major; the result
- * does not depend on it */
-void cfgpp_igemm_set_n_major(int mode); /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
+/* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
+ * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
+ * 21..23 = register-staged 1..3 */
+void cfgpp_igemm_force_config(int cfg);
+void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
+/* diagnostics: with a forced config, K-split every tile of a plain-store launch this many ways (0 = off) */
+void cfgpp_igemm_force_split(int s);
+/* big-tile K-split rule (M x N too small for 8-wave tiles to fill the chip, K long): least K-tiles (of 64) per slice for the
+ * rule to fire; 0 = rule off.  Rule-based, so results never depend on tile tuning. */
+void cfgpp_igemm_set_big_split(int min_kt);
+/* tile walk of the implicit GEMM: -1 (default) by operand bytes / the tuner's pin, 0 always M-major, 1 always N-major; the
+ * result does not depend on it */
+void cfgpp_igemm_set_n_major(int mode);
+/* in-situ tuning candidates: bit c set = tile config c may be pinned, bit 31 = the tile-walk stage runs (default: all) */
+void cfgpp_igemm_set_tune_mask(unsigned mask);
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins
  * the fastest; results are bit-identical across candidates, K-split launches stay rule-based.  0: fixed heuristic. */

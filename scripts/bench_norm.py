@@ -12,7 +12,7 @@ def timeit(fn, iters=30):
     s.record()
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / iters * 1e-3
-for (N, C, hw) in SHAPES:
+for (N, C, hw) in ([] if "--ln-only" in sys.argv else SHAPES):
     x = torch.randn(N, hw + 2, hw + 2, C, device="cuda", dtype=torch.float16)
     g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
     res = []
@@ -26,3 +26,18 @@ for (N, C, hw) in SHAPES:
         res.append(f"mode{mode}: {dt*1e6:6.1f} us {4.0*N*hw*hw*C/dt/1e12:5.2f} TB/s(4B/el) dev {dev:.1e}")
     H.lib().cfgpp_groupnorm_set_mode(0)
     print(f"gn rows={N:2d} C={C:4d} hw={hw:3d}  " + "   ".join(res), flush=True)
+
+# LayerNorm: rows in flight per wave (1 = the round-1 kernel's schedule); same per-row arithmetic -> bit-identical
+for (rows, C) in [(65536, 320), (16384, 640), (4096, 1280), (1024, 1280), (65536, 640), (16384, 1280), (8192, 640), (2048, 1280)]:
+    x = torch.randn(rows, C, device="cuda", dtype=torch.float16) * 2 + 0.3
+    g = torch.randn(C, device="cuda"); b = torch.randn(C, device="cuda")
+    res, ref = [], None
+    for rpw in (1, 2, 4, 0):
+        H.lib().cfgpp_layernorm_set_rows_per_wave(rpw)
+        out = H.layernorm(x, g, b)
+        if ref is None: ref = out.clone()
+        same = bool(torch.equal(out, ref))
+        dt = timeit(lambda: H.layernorm(x, g, b))
+        res.append(f"rpw{rpw}: {dt*1e6:6.1f} us {4.0*rows*C/dt/1e12:5.2f} TB/s same={same}")
+    H.lib().cfgpp_layernorm_set_rows_per_wave(0)
+    print(f"ln rows={rows:6d} C={C:4d}  " + "   ".join(res), flush=True)

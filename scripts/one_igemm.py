@@ -5,11 +5,13 @@ import hip_ops as H
 SH = {"conv_l0_640in": ("conv", 16, 64, 640, 320), "conv_l0_320": ("conv", 16, 64, 320, 320), "conv_l1_640": ("conv", 16, 32, 640, 640),
       "conv_l2_1280": ("conv", 16, 16, 1280, 1280), "lin_m4096_1280": ("lin", 4, 32, 1280, 1280), "lin_m4096_ffout": ("lin", 4, 32, 5120, 1280),
       "geglu_m4096": ("geglu", 4, 32, 1280, 10240), "geglu_l0": ("geglu", 16, 64, 320, 2560),
+      "conv_m2048_1280": ("conv", 2, 32, 1280, 1280), "conv_m8192_640": ("conv", 2, 64, 640, 640), "lin_m2048_ffout": ("lin", 2, 32, 5120, 1280),
       "heads_m4096": ("heads", 4, 32, 1280, 3840), "heads_l0": ("heads", 16, 64, 320, 960), "heads_l1": ("heads", 16, 32, 640, 1920)}
 kind, R, hw, Cin, N = SH[sys.argv[1]]; cfg = int(sys.argv[2]); iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 M = R * hw * hw
 H.lib().cfgpp_igemm_force_config(cfg)
 H.lib().cfgpp_igemm_set_n_major(int(os.environ.get("N_MAJOR", "-1")))
+H.lib().cfgpp_igemm_force_split(int(os.environ.get("SPLIT", "0")))
 H.lib().cfgpp_igemm_set_staged_epilogue(int(os.environ.get("STAGED", "1")))
 if kind == "conv":
     K = 9 * Cin
@@ -39,4 +41,4 @@ s.record()
 for _ in range(iters): fn()
 e.record(); torch.cuda.synchronize()
 dt = s.elapsed_time(e) / iters * 1e-3
-print(f"{sys.argv[1]} cfg{cfg}: {dt*1e6:.1f} us  {2.0*M*N*K/dt/1e12:.0f} TF/s", flush=True)
+print(f"{sys.argv[1]} cfg{cfg} split{os.environ.get('SPLIT', '0')}: {dt*1e6:.1f} us  {2.0*M*N*K/dt/1e12:.0f} TF/s", flush=True)

@@ -9,6 +9,11 @@ hw = int(sys.argv[3]) if len(sys.argv) > 3 else None
 staging = int(os.environ.get("STAGING", "1"))
 _lib.load().cfgpp_igemm_set_staging(staging)
 _lib.load().cfgpp_igemm_set_autotune(int(os.environ.get("AUTOTUNE", "1")))
+# A/B switches: TUNE_MASK=0x5f2 = the round-2 mid-round candidate set without the tile-walk stage; BIG_SPLIT=0 turns the
+# big-tile K-split rule off; LN_RPW = LayerNorm rows per wave
+_lib.load().cfgpp_igemm_set_tune_mask(int(os.environ.get("TUNE_MASK", "0xffffffff"), 0))
+_lib.load().cfgpp_igemm_set_big_split(int(os.environ.get("BIG_SPLIT", "32")))
+_lib.load().cfgpp_layernorm_set_rows_per_wave(int(os.environ.get("LN_RPW", "0")))
 eng = HipEngine(name, max_batch=rows // 2, latent_hw=(hw, hw) if hw else None)
 cfg = eng.cfg
 B = rows // 2
@@ -36,3 +41,5 @@ e0.record()
 for _ in range(10): eng.predict(z, 500.0)
 e1.record(); torch.cuda.synchronize()
 print(f"# wall {e0.elapsed_time(e1)/10:.2f} ms/forward (10 back-to-back predict() calls)")
+pins = collections.Counter(eng.unet.export_tuning())
+print("# pinned hints (tile config | walk << 6 : launches): " + ", ".join(f"{k}:{v}" for k, v in sorted(pins.items())))

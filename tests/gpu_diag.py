@@ -99,7 +99,7 @@ def t_geglu(M=260, C=64):
     ref = v * F.gelu(g)
     wp, bp = H.pack_geglu(w, b)
     out = {}
-    for c in (1, 2, 4, 6, 10):
+    for c in (1, 2, 4, 6, 10, 12, 14):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
         out[f"cfg{c}"] = H.err_stats(got, ref)
@@ -168,11 +168,20 @@ def t_big():
     wl = rnd(640, 256, scale=1 / 16, seed=86)
     bl = rnd(640, scale=0.1, seed=87)
     refl = a @ wl.t() + bl
-    for c in (4, 5, 6, 7, 8, 10):     # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M
+    # short K (1 .. 3 K-tiles): fewer tiles than the deeper rings have stages
+    shortk = []
+    for K in (64, 128, 192):
+        ak, wk = rnd(300, K, seed=88 + K), rnd(320, K, scale=K ** -0.5, seed=89 + K)
+        shortk.append((K, ak, wk, ak @ wk.t()))
+    # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
+        if c in (9, 11, 12, 14):
+            for K, ak, wk, rk in shortk:
+                out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
     return out
 
@@ -194,6 +203,16 @@ def t_tail():
             got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 20, 16, 1, None, 0, H.to_pn(res))
             out[f"conv_tail{on}_cfg{c}"] = H.err_stats(H.from_pn(got), ref)
     H.lib().cfgpp_igemm_set_tail_split(1)
+    # forced K-split of the 8-wave / 128x160 tiles (the big-tile rule's path): conv + bias + residual, N = 320
+    w3 = rnd(320, 256, 3, 3, scale=(9 * 256) ** -0.5, seed=69)
+    b3 = rnd(320, scale=0.1, seed=70)
+    res3 = rnd(2, 320, 20, 16, seed=71)
+    ref3 = F.conv2d(x, w3, b3, padding=1) + res3
+    for c, S in ((8, 2), (5, 4), (7, 3), (4, 2)):
+        H.lib().cfgpp_igemm_force_config(c); H.lib().cfgpp_igemm_force_split(S)
+        got = H.conv3x3(H.to_pn(x), H.pack_conv3(w3), b3.to(H.DEV), 20, 16, 1, None, 0, H.to_pn(res3))
+        out[f"conv_cfg{c}_split{S}"] = dict(H.err_stats(H.from_pn(got), ref3), halo_zero=H.halo_is_zero(got))
+    H.lib().cfgpp_igemm_force_split(0)
     a = rnd(300, 2048, seed=64)
     wg = rnd(8 * 64, 2048, scale=2048 ** -0.5, seed=65)
     bg = rnd(8 * 64, scale=0.1, seed=66)
@@ -276,13 +295,17 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     w = rnd(3 * C, C, scale=C ** -0.5, seed=37)
     d = C // nheads
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
-    hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
     out = {}
-    out["q"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
-    out["k"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
-    out["vt"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
-    out["pad_zero"] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :d, tokens:].abs().sum() == 0 and hvt[:, d + 1:].abs().sum() == 0)
+    for c in (0, 7, 9, 11, 12, 14):          # heuristic tile, 128x160 and the 3- / 4-stage ring tiles (LDS-staged heads epilogue)
+        H.lib().cfgpp_igemm_force_config(c)
+        hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
+        sfx = "" if c == 0 else f"_cfg{c}"
+        out["q" + sfx] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+        out["k" + sfx] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
+        out["vt" + sfx] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+        out["pad_zero" + sfx] = bool(hq[:, tokens:].abs().sum() == 0 and hq[:, :, d:].abs().sum() == 0 and hvt[:, :d, tokens:].abs().sum() == 0 and hvt[:, d + 1:].abs().sum() == 0)
+    H.lib().cfgpp_igemm_force_config(0)
     return out
 
 
