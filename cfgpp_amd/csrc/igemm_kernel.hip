@@ -839,7 +839,9 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
         int S = 0;
         if (a_in.split >= 2 && a.epi == EPI_STORE) S = a_in.split < KT ? a_in.split : KT;
         else if (g_tail_split && a_in.allow_split && (WTM == 64 && WTN == 64) && a.epi == EPI_STORE && T * 2 <= slots && KT >= 32) {
-            S = (slots + T - 1) / T;                       // one full round
+            // at most ONE round of resident workgroups: rounding up (80 tiles x 7 slices = 560 workgroups on 512 slots) left
+            // a second round of 48 stragglers as long as the first (g_tail_split == 2 keeps that for A/B)
+            S = g_tail_split == 2 ? (slots + T - 1) / T : slots / T;
             if (KT / S < 12) S = KT / 12;
             if (S > 16) S = 16;
         }
@@ -877,7 +879,7 @@ static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
 extern "C" void cfgpp_igemm_set_staging(int glds) { g_staging = glds ? 1 : 0; }
-extern "C" void cfgpp_igemm_set_tail_split(int on) { g_tail_split = on ? 1 : 0; }
+extern "C" void cfgpp_igemm_set_tail_split(int on) { g_tail_split = on == 2 ? 2 : on ? 1 : 0; }
 
 static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
     bool glds = g_staging != 0;
@@ -903,6 +905,7 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 11: return launch_cfg<4, 1, 32, 160, true, 4>(a, stream); // 128 x 160, 4 stages (147 KB)
         case 12: return launch_cfg<2, 2, 64, 64, true, 3>(a, stream);  // 128 x 128, 3 stages (96 KB)
         case 14: return launch_cfg<4, 2, 64, 64, true, 3>(a, stream);  // 256 x 128, 3 stages (144 KB)
+        case 15: return launch_cfg<2, 4, 64, 64, true, 3>(a, stream);  // 128 x 256, 3 stages (144 KB)
         // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
@@ -920,7 +923,10 @@ static int g_autotune = 1;
 extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
-static int g_big_split_min_kt = 32;    // big-tile K-split rule: least K-tiles per slice (0 = rule off)
+// big-tile K-split rule: least K-tiles per slice (0 = rule off, the default: inside a forward the 3-stage 256 x 128 tile the
+// tuner pins for these launches beat it, 751 vs 656 TF/s on the 16x16-level convs - profiles/r02/ab/igemm_insitu_run6.txt -
+// although the split wins 8 .. 21 % when the same launch is timed alone with hot caches)
+static int g_big_split_min_kt = 0;
 extern "C" void cfgpp_igemm_set_big_split(int min_kt) { g_big_split_min_kt = min_kt > 0 ? min_kt : 0; }
 int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_staging != 0; }
 static unsigned g_tune_mask = 0xffffffffu;   // bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs
@@ -982,7 +988,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         const bool rule_splits = cfg == 1 && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t128 * 2 <= 512;
         const int h = a.cfg_hint & 63;
-        const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
+        const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || h == 15 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }

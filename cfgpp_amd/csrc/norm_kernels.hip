@@ -575,8 +575,9 @@ int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* 
     CFGPP_REQUIRE(x && y && gamma && beta && rows > 0, "layernorm: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int need = cdiv(C / 4, 64);
-    // rows per wave: as many (4 / 2 / 1) as still leave >= 16 waves per CU on the 256 CUs
-    const int rpw = g_ln_rpw > 0 ? g_ln_rpw : (rows >= 4L * 4096 ? 4 : rows >= 2L * 4096 ? 2 : 1);
+    // rows per wave: 2 for the 640-byte rows of the C = 320 level when there are enough rows to keep the CUs full
+    // (measured 25.3 -> 22.4 us at 65536 rows; flat or worse for longer rows and at 4 rows per wave)
+    const int rpw = g_ln_rpw > 0 ? g_ln_rpw : (C <= 320 && rows >= 2L * 4096 ? 2 : 1);
 #define LN_LAUNCH(MV, RP) hipLaunchKernelGGL((layernorm_kernel<MV, RP>), dim3(cdiv(rows, 4 * RP)), dim3(256), 0, s, \
                                              (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps)
 #define LN_BY_RPW(MV) do { if (rpw >= 4) LN_LAUNCH(MV, 4); else if (rpw == 2) LN_LAUNCH(MV, 2); else LN_LAUNCH(MV, 1); } while (0)

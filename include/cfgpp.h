@@ -217,14 +217,16 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
- * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
+ * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128, 14 = 256x128 and 15 = 128x256
+ * on 3 stages;
  * 21..23 = register-staged 1..3 */
 void cfgpp_igemm_force_config(int cfg);
-void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1) */
+void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1); 2 = the
+                                           * round-1 slice count (rounded up: a second partial round of workgroups), for A/B */
 /* diagnostics: with a forced config, K-split every tile of a plain-store launch this many ways (0 = off) */
 void cfgpp_igemm_force_split(int s);
 /* big-tile K-split rule (M x N too small for 8-wave tiles to fill the chip, K long): least K-tiles (of 64) per slice for the
- * rule to fire; 0 = rule off.  Rule-based, so results never depend on tile tuning. */
+ * rule to fire; 0 = rule off (default - see csrc/igemm_kernel.hip).  Rule-based, so results never depend on tile tuning. */
 void cfgpp_igemm_set_big_split(int min_kt);
 /* tile walk of the implicit GEMM: -1 (default) by operand bytes / the tuner's pin, 0 always M-major, 1 always N-major; the
  * result does not depend on it */
