@@ -905,9 +905,8 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 11: return launch_cfg<4, 1, 32, 160, true, 4>(a, stream); // 128 x 160, 4 stages (147 KB)
         case 12: return launch_cfg<2, 2, 64, 64, true, 3>(a, stream);  // 128 x 128, 3 stages (96 KB)
         case 14: return launch_cfg<4, 2, 64, 64, true, 3>(a, stream);  // 256 x 128, 3 stages (144 KB)
-        // 128 x 128 as 8 waves of 32 x 64 on 2 stages (64 KB): two 8-wave workgroups per CU, so one's prologue / epilogue
-        // runs under the other's MFMAs - for the short-K launches (K = 320 .. 640: 5 .. 10 K-tiles, no steady state)
-        case 17: return launch_cfg<4, 2, 32, 64, true>(a, stream);
+        // (measured and not kept as tuner candidates, profiles/r02/ab/igemm_insitu_run8.txt: 128 x 256 on 3 stages, 128 x 128 as
+        //  8 waves of 32 x 64 with two workgroups per CU, 256 x 64 - each pinned for 0 .. 2 launches of a forward)
         // 256 x 320 with the 8 waves stacked along M (32 x 320 per wave, 10 accumulator tiles): a wave holds whole
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
@@ -923,8 +922,10 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
 // not depend on the choice (bit-identical); K-split launches (different summation order) stay rule-based.
 static int g_autotune = 1;
 extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
-static int g_split_cfg = 1;            // tile of the rule-based K-split launches: 1 (128 x 128, 2 stages), 12 (3 stages) or 14 (256 x 128, 3 stages)
-extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 12 || cfg == 14) ? cfg : 1; }
+// tile of the rule-based K-split launches: 14 (256 x 128 on 3 stages; 8x8-level convs 525 -> 619 TF/s in situ against the
+// 2-stage 128 x 128 tile, profiles/r02/ab/igemm_insitu_run8.txt), 1 (128 x 128, 2 stages) or 12 (128 x 128, 3 stages)
+static int g_split_cfg = 14;
+extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
 // big-tile K-split rule: least K-tiles per slice (0 = rule off, the default: inside a forward the 3-stage 256 x 128 tile the
@@ -994,7 +995,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const long t_rule = cfg == 14 ? (long)cdiv(a.M, 256) * cdiv(a.N, 128) : t128;
         const bool rule_splits = (cfg == 1 || cfg == 12 || cfg == 14) && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t_rule * 2 <= (cfg == 1 ? 512 : 256);
         const int h = a.cfg_hint & 63;
-        const bool valid = (h == 1 || h == 2 || h == 4 || h == 6 || h == 12 || h == 14 || h == 17 || (h == 10 && a.epi == EPI_GEGLU) ||
+        const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }

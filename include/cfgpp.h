@@ -217,13 +217,12 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
- * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages,
- * 17 = 128x128 as 8 waves (two workgroups per CU);
+ * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
  * 21..23 = register-staged 1..3 */
 void cfgpp_igemm_force_config(int cfg);
 void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1); 2 = the
                                            * round-1 slice count (rounded up: a second partial round of workgroups), for A/B */
-/* tile of the rule-based K-split launches: 1 (default) = 128x128 on 2 stages, 12 = on 3 stages, 14 = 256x128 on 3 stages */
+/* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */
 void cfgpp_igemm_set_split_tile(int cfg);
 /* diagnostics: with a forced config, K-split every tile of a plain-store launch this many ways (0 = off) */
 void cfgpp_igemm_force_split(int s);

@@ -2,7 +2,7 @@
 # round-2 final GPU run: PMC passes over UNet-only forwards (the population bench.py's roofline is computed on), the four
 # benchmark workloads, rocprofv3 kernel stats of the default bench command, per-launch profiles, the full -m gpu suite.
 set -u
-OUT=gpurun_out/r02_final; mkdir -p $OUT profiles/r02
+OUT=gpurun_out/r02_final2; mkdir -p $OUT profiles/r02
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 pmc_config() {   # name rows bench_config batch

@@ -99,7 +99,7 @@ def t_geglu(M=260, C=64):
     ref = v * F.gelu(g)
     wp, bp = H.pack_geglu(w, b)
     out = {}
-    for c in (1, 2, 4, 6, 10, 12, 14, 17):
+    for c in (1, 2, 4, 6, 10, 12, 14):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
         out[f"cfg{c}"] = H.err_stats(got, ref)
@@ -173,13 +173,13 @@ def t_big():
     for K in (64, 128, 192):
         ak, wk = rnd(300, K, seed=88 + K), rnd(320, K, scale=K ** -0.5, seed=89 + K)
         shortk.append((K, ak, wk, ak @ wk.t()))
-    # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings; 17: 128x128 as 8 waves
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 17):
+    # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 14, 17):
+        if c in (9, 11, 12, 14):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
@@ -208,7 +208,7 @@ def t_tail():
     b3 = rnd(320, scale=0.1, seed=70)
     res3 = rnd(2, 320, 20, 16, seed=71)
     ref3 = F.conv2d(x, w3, b3, padding=1) + res3
-    for c, S in ((8, 2), (5, 4), (7, 3), (4, 2)):
+    for c, S in ((8, 2), (5, 4), (7, 3), (4, 2), (14, 3), (12, 2)):      # 14: the tile the K-split rule uses
         H.lib().cfgpp_igemm_force_config(c); H.lib().cfgpp_igemm_force_split(S)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w3), b3.to(H.DEV), 20, 16, 1, None, 0, H.to_pn(res3))
         out[f"conv_cfg{c}_split{S}"] = dict(H.err_stats(H.from_pn(got), ref3), halo_zero=H.halo_is_zero(got))
@@ -297,7 +297,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
     out = {}
-    for c in (0, 7, 9, 11, 12, 14, 17):      # heuristic tile, 128x160 and the 3- / 4-stage ring tiles (LDS-staged heads epilogue)
+    for c in (0, 7, 9, 11, 12, 14):          # heuristic tile, 128x160 and the 3- / 4-stage ring tiles (LDS-staged heads epilogue)
         H.lib().cfgpp_igemm_force_config(c)
         hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
         sfx = "" if c == 0 else f"_cfg{c}"

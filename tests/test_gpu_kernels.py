@@ -92,7 +92,7 @@ def test_heads_projection_scatter(diag):
     diag.t_heads()
     r = diag.RESULTS["heads_projection"]
     assert "error" not in r, r.get("error")
-    for sfx in ("", "_cfg7", "_cfg9", "_cfg11", "_cfg12", "_cfg14", "_cfg17"):      # heuristic tile + the tiles the tuner may pin
+    for sfx in ("", "_cfg7", "_cfg9", "_cfg11", "_cfg12", "_cfg14"):      # heuristic tile + the tiles the tuner may pin
         assert r["pad_zero" + sfx], sfx
         for k in ("q", "k", "vt"):
             assert r[k + sfx]["rel_l2"] < REL, (k, sfx, r[k + sfx])
