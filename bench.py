@@ -159,8 +159,8 @@ PROFILE_ROUND = "r02"
 
 def roofline_block(eng, config, B, dev, rnd):
     """Dominant kernel = the implicit-GEMM conv/linear kernel.  `achieved` = algorithmic FLOPs of its launches in one
-    UNet forward / their summed HIP-event durations on the launch stream (three profiled forwards right after the timed
-    region, `cfgpp_unet_profile`).  Live as well: attention TFLOP/s, and algorithmic GB/s of the HBM-bound families
+    UNet forward / their summed HIP-event durations on the launch stream (`cfgpp_unet_profile`: three profiled forwards
+    right after the timed region, per launch the fastest of the three; all three per-family sums are in the JSON line).  Live as well: attention TFLOP/s, and algorithmic GB/s of the HBM-bound families
     (GroupNorm / LayerNorm at 4 B per element, the fused CFG++ step at 16 B per latent element).  From the committed
     rocprofv3 PMC passes of the SAME population (UNet-only forwards at this batch with the tiles this build's tuner
     pins; scripts/pmc_unet.py + scripts/pmc_summary.py -> profiles/<round>/pmc_<config>_b<B>.json): `traffic` (HBM
@@ -169,20 +169,34 @@ def roofline_block(eng, config, B, dev, rnd):
     import re
     rows = 2 * B
     z = torch.randn((B, 4, eng.H, eng.W), device=dev)
-    fam = {}
-    gb = {"groupnorm": [0.0, 0.0], "layernorm": [0.0, 0.0]}      # [bytes, seconds]
+    KIND = {"0": "igemm", "1": "attention", "2": "norm", "3": "small"}
+    passes, flops, launches = [], {}, {}
     for t in (981.0, 501.0, 21.0):
         pr = eng.unet.profile(z, t, detail=True)
-        for k in ("igemm", "attention", "norm", "small"):
-            f = fam.setdefault(k, dict(ms=0.0, flops=0.0, launches=pr[k]["launches"]))
-            f["ms"] += pr[k]["ms"]
-            f["flops"] += pr[k]["flops"]
-        for line in pr["detail"].strip().split("\n"):
-            parts = line.split("\t")
-            m = re.match(r"(groupnorm|layernorm) HW=(\d+) C=(\d+)", parts[2]) if len(parts) >= 4 else None
-            if m:
-                gb[m.group(1)][0] += 4.0 * rows * int(m.group(2)) * int(m.group(3))
-                gb[m.group(1)][1] += float(parts[3]) * 1e-6
+        for k in KIND.values():
+            flops[k], launches[k] = pr[k]["flops"], pr[k]["launches"]
+        passes.append([line.split("\t") for line in pr["detail"].strip().split("\n")])
+    # Per launch: the FASTEST of the three profiled passes.  A launch's duration does not depend on t, but an interval
+    # between two events also contains whatever kept the stream waiting before the launch was enqueued: the round-2
+    # final run had single ~57 ms host stalls land inside one attention (SD1.5) / one igemm (SDXL) interval.
+    fam = {k: dict(ms=0.0, flops=flops[k], launches=launches[k]) for k in KIND.values()}
+    gb = {"groupnorm": [0.0, 0.0], "layernorm": [0.0, 0.0]}      # [bytes, seconds]
+    pass_ms = [{k: 0.0 for k in KIND.values()} for _ in passes]
+    for i, parts in enumerate(passes[0]):
+        if len(parts) < 4:
+            continue
+        us_all = [float(p[i][3]) for p in passes if i < len(p) and len(p[i]) >= 4]
+        us = min(us_all)
+        kind = KIND.get(parts[1], "small")
+        fam[kind]["ms"] += us * 1e-3
+        for q, u in enumerate(us_all):
+            pass_ms[q][kind] += u * 1e-3
+        m = re.match(r"(groupnorm|layernorm) HW=(\d+) C=(\d+)", parts[2])
+        if m:
+            gb[m.group(1)][0] += 4.0 * rows * int(m.group(2)) * int(m.group(3))
+            gb[m.group(1)][1] += us * 1e-6
+    log("profiled passes, ms per family: " + " | ".join(", ".join(f"{k} {v:.2f}" for k, v in pm.items()) for pm in pass_ms)
+        + " | per-launch minimum: " + ", ".join(f"{k} {v['ms']:.2f}" for k, v in fam.items()))
     # fused CFG++ step kernel: 16 B per latent element (4 z in, 2 + 2 eps in, 4 z0t out, 4 z out)
     from cfgpp_amd import engine as E
     zz = torch.randn((B, 4, eng.H, eng.W), device=dev)
@@ -198,7 +212,7 @@ def roofline_block(eng, config, B, dev, rnd):
     torch.cuda.synchronize()
     step_s = e0.elapsed_time(e1) / 20 * 1e-3
     ig = fam["igemm"]
-    ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+    ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12                     # flops of ONE forward / per-launch-minimum time of one forward
     pmc = None
     pf = os.path.join(ROOT, "profiles", rnd, f"pmc_{config}_b{B}.json")
     if os.path.exists(pf):
@@ -212,8 +226,9 @@ def roofline_block(eng, config, B, dev, rnd):
            "traffic_unit": "HBM bytes per igemm launch (rocprofv3 PMC passes over UNet-only forwards at this batch)",
            "algorithmic_bytes_per_launch": None if pmc is None else pmc["igemm"].get("algorithmic_bytes_per_launch"),
            "mfma_util": None if pmc is None else {k: pmc[k].get("mfma_util") for k in ("igemm", "attention") if k in pmc},
-           "launches_per_forward": ig["launches"], "avg_launch_us": round(ig["ms"] / 3 / max(ig["launches"], 1) * 1e3, 2),
-           "per_family_ms_per_forward": {k: round(v["ms"] / 3, 3) for k, v in fam.items()},
+           "launches_per_forward": ig["launches"], "avg_launch_us": round(ig["ms"] / max(ig["launches"], 1) * 1e3, 2),
+           "per_family_ms_per_forward": {k: round(v["ms"], 3) for k, v in fam.items()},
+           "per_family_ms_per_profiled_pass": [{k: round(v, 3) for k, v in pm.items()} for pm in pass_ms],
            "attention_TFLOPs": round(fam["attention"]["flops"] / (fam["attention"]["ms"] * 1e-3) / 1e12, 1),
            "hbm_GBps": {"groupnorm": round(gb["groupnorm"][0] / max(gb["groupnorm"][1], 1e-12) / 1e9, 1),
                         "layernorm": round(gb["layernorm"][0] / max(gb["layernorm"][1], 1e-12) / 1e9, 1),

@@ -48,11 +48,17 @@ def due(step: int, frequency: int) -> bool:
     return step == 0 or (step + 1) % frequency == 0
 
 
-def save_image(img: torch.Tensor, path) -> None:
+def save_image(img: torch.Tensor, path, normalize: bool = False) -> None:
     """``img`` [B,3,H,W] with values in [0,1] -> 8-bit RGB file(s); batch element b > 0 gets the suffix ``_b``
-    (a single image keeps the given name)."""
+    (a single image keeps the given name).  ``normalize=True`` stretches the tensor's [min, max] to [0, 1] first -
+    what ``torchvision.utils.save_image(..., normalize=True)`` does to the results the reference's example scripts save
+    (examples/text_to_img.py:56, inversion.py:55, text_to_mscoco.py:62); the draw_* callbacks save without it."""
     path = Path(path)
-    pixels = img.detach().float().clamp(0, 1).mul(255.0).add(0.5).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+    img = img.detach().float()
+    if normalize:
+        low, high = float(img.min()), float(img.max())
+        img = (img.clamp(low, high) - low) / max(high - low, 1e-5)
+    pixels = img.clamp(0, 1).mul(255.0).add(0.5).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
     for b, frame in enumerate(pixels):
         target = path if len(pixels) == 1 else path.with_name(f"{path.stem}_{b}{path.suffix}")
         try:

@@ -66,7 +66,7 @@ def main(argv=None, solver_kwargs=None) -> None:
         from cfgpp_amd.latent_diffusion import get_solver
         solver = get_solver(args.method, **kw)
         result = solver.sample(prompt=[args.null_prompt, args.prompt], src_img=img, cfg_guidance=args.cfg_guidance, callback_fn=None)
-    save_image(result, args.workdir / "result" / "reconstruct.png")
+    save_image(result, args.workdir / "result" / "reconstruct.png", normalize=True)
     print(f"saved {args.workdir / 'result' / 'reconstruct.png'}")
 
 

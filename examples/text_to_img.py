@@ -9,7 +9,8 @@ default = seeded synthetic weights, because no checkpoint exists offline), ``--b
 seed, seed+1, ... in one UNet batch of 2B rows) and ``--draw`` (the reference keeps its ComposeCallback
 commented out).  Text goes through ``solver.text_encoder`` (synthetic embeddings unless a CLIP callable is
 plugged in, cfgpp_amd/conditioning.py).  Reference behaviour kept: CPU-generator initial latent from
-``--seed``, default null prompt, 1024x1024 target for SDXL, result saved to <workdir>/result/generated.png.
+``--seed``, default null prompt, 1024x1024 target for SDXL, result saved (min-max normalised, as torchvision's
+``save_image(normalize=True)`` does there) to <workdir>/result/generated.png.
 """
 from __future__ import annotations
 
@@ -66,7 +67,7 @@ def main(argv=None, solver_kwargs=None) -> None:
 
     for i in range(result.shape[0]):
         name = "generated.png" if result.shape[0] == 1 else f"generated_{i}.png"
-        save_image(result[i:i + 1], args.workdir / "result" / name)
+        save_image(result[i:i + 1], args.workdir / "result" / name, normalize=True)
     print(f"saved {result.shape[0]} image(s) to {args.workdir / 'result'}")
 
 

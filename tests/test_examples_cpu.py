@@ -28,6 +28,49 @@ def test_text_to_img_cli_writes_pngs(tmp_path):
     assert len(list((tmp_path / "record").rglob("*.png"))) > 0          # draw_* callbacks fired
 
 
+def test_mscoco_cli_one_image_per_caption(tmp_path, monkeypatch):
+    """twin of the reference's examples/text_to_mscoco.py: blank lines skipped, files named by caption index, batches of
+    --batch captions (ragged last batch), --limit; under a 2-rank environment each rank writes its contiguous shard"""
+    from PIL import Image
+    import text_to_mscoco
+    caps = tmp_path / "caps.txt"
+    caps.write_text("a cat\n\n  a dog on a sofa  \na red bus\n\na plate of food\ntwo birds\n")
+    assert text_to_mscoco.read_captions(caps) == ["a cat", "a dog on a sofa", "a red bus", "a plate of food", "two birds"]
+    out = tmp_path / "coco"
+    kw = dict(engine=MockEngine(_unet, (8, 8)), vae=StubVAE(0.18215), latent_hw=(8, 8))
+    base = ["--prompt_dir", str(caps), "--method", "ddim_cfg++", "--cfg_guidance", "0.6", "--NFE", "2", "--device", "cpu", "--no_draw"]
+    n = text_to_mscoco.main(base + ["--batch", "2", "--workdir", str(out)], solver_kwargs=kw)
+    assert n == 5 and sorted(p.name for p in out.glob("*.png")) == [f"{i:05d}.png" for i in range(5)]
+    assert Image.open(out / "00004.png").size == (64, 64)
+    # batch 1 == the reference's loop; --limit
+    out1 = tmp_path / "coco1"
+    kw = dict(engine=MockEngine(_unet, (8, 8)), vae=StubVAE(0.18215), latent_hw=(8, 8))
+    assert text_to_mscoco.main(base + ["--limit", "3", "--workdir", str(out1)], solver_kwargs=kw) == 3
+    assert sorted(p.name for p in out1.glob("*.png")) == ["00000.png", "00001.png", "00002.png"]
+    # two ranks: contiguous shards 0..2 and 3..4, same file names as the single-process run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    for rank, expect in ((0, [0, 1, 2]), (1, [3, 4])):
+        monkeypatch.setenv("RANK", str(rank))
+        outr = tmp_path / f"coco_r{rank}"
+        kw = dict(engine=MockEngine(_unet, (8, 8)), vae=StubVAE(0.18215), latent_hw=(8, 8))
+        assert text_to_mscoco.main(base + ["--batch", "2", "--workdir", str(outr)], solver_kwargs=kw) == len(expect)
+        assert sorted(p.name for p in outr.glob("*.png")) == [f"{i:05d}.png" for i in expect]
+        for i in expect:      # explicit per-caption seeds: a caption's image does not depend on how the captions were sharded
+            assert np.array_equal(np.asarray(Image.open(outr / f"{i:05d}.png")), np.asarray(Image.open(out / f"{i:05d}.png")))
+
+
+def test_save_image_normalize_matches_torchvision_rule(tmp_path):
+    from PIL import Image
+    from cfgpp_amd.callback_util import save_image
+    x = torch.rand(1, 3, 4, 5) * 0.5 + 0.2
+    save_image(x, tmp_path / "n.png", normalize=True)
+    lo, hi = float(x.min()), float(x.max())
+    want = ((x - lo) / (hi - lo)).mul(255).add(0.5).clamp(0, 255).to(torch.uint8)[0].permute(1, 2, 0).numpy()
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "n.png")), want)
+    save_image(x, tmp_path / "p.png")
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "p.png")), x.mul(255).add(0.5).to(torch.uint8)[0].permute(1, 2, 0).numpy())
+
+
 def test_inversion_cli_reconstructs(tmp_path):
     from PIL import Image
     import inversion
