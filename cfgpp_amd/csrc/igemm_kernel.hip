@@ -798,6 +798,268 @@ igemm_reduce_kernel(const IGemmArgs p) {
     igemm_epilogue<1, 1>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane);
 }
 
+// ---- 128 x 160 tile as EIGHT waves of 32 x 80 on v_mfma_f32_16x16x32_f16 --------------------------------------------
+// The in-situ A/Bs of round 2 rewarded three properties at once - 8 waves per workgroup (two per SIMD), >= 3 LDS stages
+// (two K-tiles of lookahead: inside a forward the operands come from HBM / the Infinity Cache) and one tile per CU - and no
+// 32 x 32 tiling has all three for the M = 4096 x N = 1280 class (half of an SDXL forward, the 16x16 level of SD1.5): 128 x 160
+// is 256 tiles but 32 x 160 waves make it a 4-wave workgroup, 256 x 128 on 8 waves is 160 tiles.  80 = 5 x 16, so the
+// 16 x 16 x 32 MFMA gives each of 8 waves a 32 x 80 slab (2 x 5 accumulator tiles of 4 registers).
+//   * operands "swapped" as in igemm_kernel: MFMA-A = weights (rows n), MFMA-B = activations (columns m); a lane then holds
+//     4 consecutive output features (n = 4 * (lane >> 4) + r) of ONE pixel (m = lane & 15);
+//   * LDS image, XOR swizzle and the LDS-DMA loader are igemm_kernel's; a fragment is rows base + (lane & 15), logical
+//     16-byte chunk 4 * s + (lane >> 4) of k-step s (two k-steps of 32 per K-tile): with 16-row-aligned bases the four
+//     16-lane groups of a ds_read_b128 hit 16 distinct bank quads (same argument as the 32-row case);
+//   * 8 waves x 8 rows = 64 rows per loader pass: 128 activation rows = 2 passes, 160 weight rows = 2 passes + one that
+//     only waves 0-3 take, so the counted vmcnt waits use the WAVE's piece count (5 or 4 per K-tile);
+//   * plain-store epilogue only (bias / temb / residual through the per-wave LDS transpose); whole tiles only (no K-split).
+// The 16 x 16 x 32 MFMA sums k in a different order than the 32 x 32 x 16 one, so this tile is NOT a tuner candidate (the
+// tuner's choices must not change results): it is used by rule (cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
+__device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
+                                                        char* stg /* wave-private, 32 * 176 bytes */) {
+    constexpr int WTN = 80, PITCH = WTN * 2 + 16, CPR = WTN / 8, NQ = (32 * CPR + 63) / 64;
+    const int c16 = lane & 15, fq = lane >> 4;
+    const int HW = p.rows_per_batch;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = mw0 + i * 16 + c16;
+        const int mc = m < p.M ? m : p.M - 1;
+        const int b = (HW > 0) ? mc / HW : 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int nl = j * 16 + 4 * fq;
+            int n = nw0 + nl;
+            n = n < p.N ? n : p.N - 4;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k] * p.out_scale;
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (p.temb) {
+                const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+                v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+            }
+            half4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+            *reinterpret_cast<half4_t*>(stg + (i * 16 + c16) * PITCH + nl * 2) = o;
+        }
+    }
+    // rows leave as 16-byte pieces; lane r (< 32) knows row r's output / residual pixel index
+    const int frow = lane & 31;
+    const int mr = mw0 + frow;
+    const int mrc = mr < p.M ? mr : p.M - 1;
+    int opix = mrc, rpix = mrc;
+    if (p.omode == 1 || p.rmode == 1) {
+        const int pp = padded_pix(mrc, HW, p.W, p.H);
+        if (p.omode == 1) opix = pp;
+        if (p.rmode == 1) rpix = pp;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = lane + 64 * q;
+        const int r = c / CPR, cc = c - r * CPR;
+        const int op = __shfl(opix, r), rp = __shfl(rpix, r);
+        const int mm = mw0 + r, n = nw0 + cc * 8;
+        if (c < 32 * CPR && mm < p.M && n < p.N) {
+            half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
+            if (p.resid) {
+                const half8_t rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
+            }
+            *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
+        }
+    }
+}
+
+template <int AMODE, int NST>
+__global__ void __launch_bounds__(512)
+igemm16_kernel(const IGemmArgs p) {
+    constexpr int BM = 128, BN = 160, RSTEP = 64;
+    constexpr int A_CH = BM / RSTEP;                // 2 loader passes over the activation rows
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int NM = 20;                          // MFMAs per wave per K-tile: 2 k-steps x (2 x 5) tiles
+    static_assert(NST >= 3 && NST <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int bid = blockIdx.x;
+    int wg;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int wq = wg / p.walk_div, wr = wg - wq * p.walk_div;
+    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const bool b3 = wid < 4;                        // (wave-uniform) this wave also loads weight rows 128 + 8 wid ..
+
+    // ---- loader state (as igemm_kernel) ----
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const int HW = p.rows_per_batch;
+    int a_pix[A_CH];
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+        int m = m0 + lrow + j * RSTEP;
+        m = m < p.M ? m : p.M - 1;
+        if constexpr (AMODE == 0) a_pix[j] = m;
+        else if constexpr (AMODE == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
+        else if constexpr (AMODE == 2) {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1 + p.ashift) * (2 * p.W + 2) + 2 * x + 1 + p.ashift;
+        } else {
+            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            a_pix[j] = (b << 22) | (y << 11) | x;
+        }
+    }
+    const int schunk = lchunk ^ ((lrow >> 1) & 7);  // the DMA stores lane-linear: swizzle the SOURCE chunk
+    const half_t* b_ptr[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int n = n0 + lrow + j * RSTEP;
+        n = n < p.N ? n : p.N - 1;
+        b_ptr[j] = p.w + (long)n * p.K + schunk * 8;
+    }
+    const int wave_row0 = wid * 8;
+
+    struct Gather { const half_t* src; int cs, Cs, dpix, dy, dx; };
+    auto gather_of = [&](int kt) {
+        Gather g;
+        int tap = 0, cc = kt << 6;
+        if (p.taps == 9) { const int cb = kt / 9; tap = kt - cb * 9; cc = cb << 6; }
+        const bool s0 = cc < p.C0;
+        g.src = s0 ? p.a0 : p.a1;
+        g.cs = s0 ? cc : cc - p.C0; g.Cs = s0 ? p.C0 : p.C1;
+        g.dy = 0; g.dx = 0;
+        if (p.taps == 9) { g.dy = tap / 3 - 1; g.dx = tap - (tap / 3) * 3 - 1; }
+        g.dpix = 0;
+        if constexpr (AMODE == 1) g.dpix = g.dy * (p.W + 2) + g.dx;
+        else if constexpr (AMODE == 2) g.dpix = g.dy * (2 * p.W + 2) + g.dx;
+        return g;
+    };
+    // piece q of K-tile kt into `stage`: q = 0, 1 activation passes; 2, 3 weight passes; 4 the half weight pass (b3 waves)
+    auto piece = [&](int q, int kt, int stage, const Gather& g) {
+        char* As = smem + stage * STAGE_BYTES;
+        char* Bs = As + BM * 128;
+        if (q < A_CH) {
+            const int j = q;
+            int pix;
+            if constexpr (AMODE == 3) {
+                const int b = a_pix[j] >> 22, y = (a_pix[j] >> 11) & 2047, x = a_pix[j] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + g.dy) >> 1) + 1) * (Ws + 2) + ((x + g.dx) >> 1) + 1;
+            } else {
+                pix = a_pix[j] + g.dpix;
+            }
+            const half_t* gp = g.src + (long)pix * g.Cs + g.cs + schunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(As + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        } else {
+            const int j = q - A_CH;
+            const half_t* gp = b_ptr[j] + ((long)kt << 6);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(Bs + (wave_row0 + j * RSTEP) * 128), 16, 0, 0);
+        }
+    };
+    // "at most n K-tiles of THIS wave's pieces still in flight"
+#define CFGPP_WAIT_TILES(n) do { if (b3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((n) * 5) : "memory");          \
+                                 else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((n) * 4) : "memory"); } while (0)
+
+    f32x4 acc[2][5];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[i][j][k] = 0.f;
+
+    // fragment reads: row = base + (lane & 15), logical chunk = 4 * s + (lane >> 4)
+    const int c16 = lane & 15, fq = lane >> 4;
+    const int fsw = c16 >> 1;
+    const int a_rd = (wm * 32 + c16) * 128;
+    const int b_rd = (wn * 80 + c16) * 128;
+
+    const int nk = p.K >> 6;
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+        if (s_ < nk) {
+            const Gather g = gather_of(s_);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) piece(q, s_, s_, g);
+            if (b3) piece(4, s_, s_, g);
+        }
+    if (nk >= NST - 1) CFGPP_WAIT_TILES(NST - 2);      // NST-1 tiles issued: the oldest has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma) {
+        constexpr bool DMA = decltype(with_dma)::value;
+        const char* As = smem + cur * STAGE_BYTES;
+        const char* Bs = As + BM * 128;
+        Gather gn = {p.a0, 0, p.C0, 0, 0, 0};
+        if constexpr (DMA) gn = gather_of(ktn);
+        // the next tile's pieces go out one by one during the first 5/8 of the MFMAs (igemm_kernel's interleave)
+        constexpr int NP = 5, SPAN = (NM * 5) / 8;
+        int issued = 0, done = 0;                        // compile-time after unrolling
+        auto after_mfma = [&]() {
+            ++done;
+            if constexpr (DMA) {
+                if (issued < NP && done * NP >= (issued + 1) * SPAN) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (issued < 4 || b3) piece(issued, ktn, nxt, gn);
+                    ++issued;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        half8_t xa[2][2], wb[2][5];
+        {
+            const int coff = (fq ^ fsw) << 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 16 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 16 * 128 + coff);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 0) {
+                const int coff = ((4 | fq) ^ fsw) << 4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xa[1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 16 * 128 + coff);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) wb[1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 16 * 128 + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
+                    after_mfma();
+                }
+        }
+        if constexpr (DMA) CFGPP_WAIT_TILES(NST - 2);   // tile kt+1 has landed: only the younger tiles' pieces are outstanding
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    int kt = 0;
+    for (; kt + NST - 1 < nk; ++kt) tile_body(kt, kt % NST, kt + NST - 1, (kt + NST - 1) % NST, std::true_type{});
+    for (; kt < nk; ++kt) tile_body(kt, kt % NST, 0, 0, std::false_type{});
+#undef CFGPP_WAIT_TILES
+
+    // the k-loop ended with vmcnt(0) + barrier: LDS is free for the per-wave transposes
+    igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
+}
+
 // ---- launch + tail scheduling ------------------------------------------------------------------
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_BYTES = 128L << 20;               // fp32 partials of one launch: T * S * BM * BN * 4 bytes must fit
@@ -875,6 +1137,41 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
 
 // forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
 // variant of the same tile (the LDS-DMA variant is the default)
+// 128 x 160 tile on 8 waves of 16x16x32 MFMAs (igemm16_kernel): whole tiles, plain-store epilogue
+static bool mf16_supports(const IGemmArgs& a) {
+    return a.epi == EPI_STORE && a.N % 160 == 0 && g_staged_epi && a.K >= 64;
+}
+template <int AMODE, int NST>
+int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
+    constexpr int smem = NST * (128 + 160) * 128;
+    static bool attr_set = false;
+    auto kern = igemm16_kernel<AMODE, NST>;
+    if (!attr_set) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    IGemmArgs a = a_in;
+    const int ntm = cdiv(a.M, 128), ntn = a.N / 160;
+    a.n_main = ntm * ntn; a.ksplit = 1; a.ws = nullptr; a.staged_epi = 1;
+    const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
+    a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
+    if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
+    a.walk_div = a.n_major ? ntm : ntn;
+    hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(512), smem, stream, a);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+template <int NST>
+int launch_mf16(const IGemmArgs& a, hipStream_t stream) {
+    switch (a.amode) {
+        case 0: return launch_mf16_amode<0, NST>(a, stream);
+        case 1: return launch_mf16_amode<1, NST>(a, stream);
+        case 2: return launch_mf16_amode<2, NST>(a, stream);
+        case 3: return launch_mf16_amode<3, NST>(a, stream);
+        default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
+    }
+}
+
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
@@ -911,6 +1208,10 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
+        // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
+        // N % 160 == 0 only - anything else falls back to the 4-wave 128 x 160 tile.  Not a tuner candidate (different k order).
+        case 18: return mf16_supports(a) ? launch_mf16<3>(a, stream) : launch_cfg<4, 1, 32, 160, true>(a, stream);
+        case 19: return mf16_supports(a) ? launch_mf16<4>(a, stream) : launch_cfg<4, 1, 32, 160, true>(a, stream);
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -926,6 +1227,8 @@ extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
 // 2-stage 128 x 128 tile, profiles/r02/ab/igemm_insitu_run8.txt), 1 (128 x 128, 2 stages) or 12 (128 x 128, 3 stages)
 static int g_split_cfg = 14;
 extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
+static int g_mf16 = 0;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
+extern "C" void cfgpp_igemm_set_mf16(int mode) { g_mf16 = (mode == 3 || mode == 4) ? mode : 0; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
 // big-tile K-split rule: least K-tiles per slice (0 = rule off, the default: inside a forward the 3-stage 256 x 128 tile the
@@ -987,6 +1290,12 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
             while (S >= 2 && KT / S < g_big_split_min_kt) --S;
             if (S >= 2 && t8 * S >= 192) { cfg = 8; a.split = S; big_split = true; }
         }
+    }
+    // 16x16x32-MFMA tile by rule (never by tuning: it sums k in a different order): plain-store launches whose 128 x 160
+    // grid is one round of at most 256 tiles and at least half of it.  Off by default (cfgpp_igemm_set_mf16).
+    if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a)) {
+        const long t7 = (long)cdiv(a.M, 128) * (a.N / 160);
+        if (t7 >= 128 && t7 <= 256) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
     }
     if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0 && !big_split) {
         const int KT = a.K >> 6;

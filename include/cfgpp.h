@@ -218,10 +218,14 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
+ * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);
  * 21..23 = register-staged 1..3 */
 void cfgpp_igemm_force_config(int cfg);
 void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1); 2 = the
                                            * round-1 slice count (rounded up: a second partial round of workgroups), for A/B */
+/* 8-wave 16x16x32-MFMA 128x160 tile for plain-store launches whose 128x160 grid is 128..256 tiles: 0 = off (default), 3 / 4 =
+ * on with that many LDS stages.  Rule-based (the tile sums k in a different order than the others, so the tuner never picks it). */
+void cfgpp_igemm_set_mf16(int mode);
 /* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */
 void cfgpp_igemm_set_split_tile(int cfg);
 /* diagnostics: with a forced config, K-split every tile of a plain-store launch this many ways (0 = off) */

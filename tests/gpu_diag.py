@@ -173,13 +173,14 @@ def t_big():
     for K in (64, 128, 192):
         ak, wk = rnd(300, K, seed=88 + K), rnd(320, K, scale=K ** -0.5, seed=89 + K)
         shortk.append((K, ak, wk, ak @ wk.t()))
-    # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14):
+    # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings;
+    # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages)
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 18, 19):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 14):
+        if c in (9, 11, 12, 14, 18, 19):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
