@@ -111,6 +111,9 @@ def load():
         raise CfgppError(
             f"{LIB_PATH} not found: build it with `python -m cfgpp_amd.build` "
             "(__graft_entry__.build()).  The HIP path has no CPU fallback.")
+    # torch first: it brings its own copy of the HIP runtime; loaded after libcfgpp_hip.so (which would pull in the system one)
+    # the process ends up with two runtimes and the engine cannot use torch's device pointers / streams
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

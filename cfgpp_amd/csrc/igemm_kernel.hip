@@ -813,7 +813,7 @@ igemm_reduce_kernel(const IGemmArgs p) {
 //     only waves 0-3 take, so the counted vmcnt waits use the WAVE's piece count (5 or 4 per K-tile);
 //   * plain-store epilogue only (bias / temb / residual through the per-wave LDS transpose); whole tiles only (no K-split).
 // The 16 x 16 x 32 MFMA sums k in a different order than the 32 x 32 x 16 one, so this tile is NOT a tuner candidate (the
-// tuner's choices must not change results): it is used by rule (cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
+// tuner's choices must not change results): it is used by rule (igemm_launch; cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
 __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
                                                         char* stg /* wave-private, 32 * 176 bytes */) {
     constexpr int WTN = 80, PITCH = WTN * 2 + 16, CPR = WTN / 8, NQ = (32 * CPR + 63) / 64;
@@ -1227,7 +1227,7 @@ extern "C" void cfgpp_igemm_set_autotune(int on) { g_autotune = on ? 1 : 0; }
 // 2-stage 128 x 128 tile, profiles/r02/ab/igemm_insitu_run8.txt), 1 (128 x 128, 2 stages) or 12 (128 x 128, 3 stages)
 static int g_split_cfg = 14;
 extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
-static int g_mf16 = 0;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
+static int g_mf16 = 4;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
 extern "C" void cfgpp_igemm_set_mf16(int mode) { g_mf16 = (mode == 3 || mode == 4) ? mode : 0; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
@@ -1292,10 +1292,12 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         }
     }
     // 16x16x32-MFMA tile by rule (never by tuning: it sums k in a different order): plain-store launches whose 128 x 160
-    // grid is one round of at most 256 tiles and at least half of it.  Off by default (cfgpp_igemm_set_mf16).
+    // grid is ONE round of 200 .. 256 tiles - the M = 4096 x N = 1280 class (16x16 level of SD1.5 at batch 8, 32x32 level of
+    // SDXL at batch 2).  In situ against the tuned 3-stage 256 x 128 tile: convs 762 -> 866 TF/s, FF-out K = 5120 693 -> 800,
+    // to_out K = 1280 436 -> 505, SD1.5 forward 21.06 -> 20.61 ms (profiles/r02/ab/igemm_mf16_run9.txt).
     if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a)) {
         const long t7 = (long)cdiv(a.M, 128) * (a.N / 160);
-        if (t7 >= 128 && t7 <= 256) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
+        if (t7 >= 200 && t7 <= 256) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
     }
     if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0 && !big_split) {
         const int KT = a.K >> 6;

@@ -223,7 +223,7 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
 void cfgpp_igemm_force_config(int cfg);
 void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K into fp32 partials + reduce (default 1); 2 = the
                                            * round-1 slice count (rounded up: a second partial round of workgroups), for A/B */
-/* 8-wave 16x16x32-MFMA 128x160 tile for plain-store launches whose 128x160 grid is 128..256 tiles: 0 = off (default), 3 / 4 =
+/* 8-wave 16x16x32-MFMA 128x160 tile for plain-store launches whose 128x160 grid is 200..256 tiles: 0 = off, 3 / 4 (default 4) =
  * on with that many LDS stages.  Rule-based (the tile sums k in a different order than the others, so the tuner never picks it). */
 void cfgpp_igemm_set_mf16(int mode);
 /* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */
