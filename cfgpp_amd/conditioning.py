@@ -64,6 +64,105 @@ class HashTokenizer:
         return out
 
 
+def _bytes_to_unicode() -> dict:
+    """the byte <-> printable-character table of byte-level BPE (GPT-2 / CLIP): printable latin-1 bytes map to
+    themselves, the other 68 bytes to code points 256 .."""
+    keep = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    table, extra = {}, 0
+    for b in range(256):
+        if b in keep:
+            table[b] = chr(b)
+        else:
+            table[b] = chr(256 + extra)
+            extra += 1
+    return table
+
+
+class ClipBpeTokenizer:
+    """The CLIP byte-level BPE tokenizer from its two files (``vocab.json``: token -> id, ``merges.txt``: one merge per
+    line after the ``#version`` header) - what ``CLIPTokenizer.from_pretrained(model_key, subfolder="tokenizer")`` loads in
+    the reference (latent_diffusion.py:92-104, latent_sdxl.py:56-75).  No vocabulary ships offline, so the solvers default
+    to ``HashTokenizer``; with the files of a real checkpoint this class gives the real ids.
+
+    Algorithm (pinned against ``transformers.CLIPTokenizer`` on the same files in tests/test_capi_and_config.py):
+    NFC -> runs of whitespace to one space -> lower case; split with CLIP's pattern (special tokens, English
+    contractions, letter runs, single digits, runs of other symbols); UTF-8 bytes -> printable characters; greedy
+    lowest-rank pair merging with ``</w>`` on the last character; unknown pieces -> ``<|endoftext|>``; ``[BOS] + ids[:75] +
+    [EOS]`` padded to 77 with the pad token (EOS for CLIP-L, "!" = id 0 for SDXL's second tokenizer)."""
+
+    PATTERN = r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"
+
+    def __init__(self, vocab, merges, pad_token: Optional[str] = None, length: int = 77):
+        """``pad_token``: None = pad with ``<|endoftext|>`` (CLIP-L); ``"!"`` for SDXL's second tokenizer.  A pad token that
+        is an ordinary vocabulary entry is also a SPECIAL token of the HF tokenizer: every occurrence in a prompt is cut out
+        before the BPE and mapped to its own id ("!!" -> [0, 0], not ["!", "!</w>"]) - a quirk of that tokenizer kept here."""
+        import json
+        import regex
+        if isinstance(vocab, (str, bytes)) or hasattr(vocab, "__fspath__"):
+            with open(vocab, "r", encoding="utf-8") as f:
+                vocab = json.load(f)
+        if isinstance(merges, (str, bytes)) or hasattr(merges, "__fspath__"):
+            with open(merges, "r", encoding="utf-8") as f:
+                lines = f.read().strip().split("\n")
+            merges = [ln for ln in lines if ln and not ln.startswith("#version")]
+        self.vocab = dict(vocab)
+        self.ranks = {tuple(m.split(" ")) if isinstance(m, str) else tuple(m): i for i, m in enumerate(merges)}
+        self.BOS, self.EOS = self.vocab["<|startoftext|>"], self.vocab["<|endoftext|>"]
+        self.VOCAB = max(self.vocab.values()) + 1
+        self.pad_id = self.EOS if pad_token is None else self.vocab[pad_token]
+        self.length = length
+        self._b2u = _bytes_to_unicode()
+        self._pat = regex.compile(self.PATTERN)
+        specials = ["<|startoftext|>", "<|endoftext|>"] + ([pad_token] if pad_token not in (None, "<|startoftext|>", "<|endoftext|>") else [])
+        self._special = regex.compile("(" + "|".join(regex.escape(t) for t in sorted(specials, key=len, reverse=True)) + ")")
+        self._special_set = set(specials)
+        self._cache = {}
+
+    def _bpe(self, piece: str) -> List[str]:
+        if piece in self._cache:
+            return self._cache[piece]
+        word = list(piece[:-1]) + [piece[-1] + "</w>"]
+        while len(word) > 1:
+            best, best_rank = None, None
+            for a, b in zip(word[:-1], word[1:]):
+                r = self.ranks.get((a, b))
+                if r is not None and (best_rank is None or r < best_rank):
+                    best, best_rank = (a, b), r
+            if best is None:
+                break
+            merged, i = [], 0
+            while i < len(word):
+                if i + 1 < len(word) and (word[i], word[i + 1]) == best:
+                    merged.append(word[i] + word[i + 1]); i += 2
+                else:
+                    merged.append(word[i]); i += 1
+            word = merged
+        self._cache[piece] = word
+        return word
+
+    def encode(self, text: str) -> List[int]:
+        """ids of one prompt without BOS / EOS / padding"""
+        import re
+        import unicodedata
+        ids = []
+        for seg in self._special.split(text):               # special tokens are cut out of the RAW text
+            if seg in self._special_set:
+                ids.append(self.vocab[seg])
+                continue
+            seg = re.sub(r"\s+", " ", unicodedata.normalize("NFC", seg)).lower()
+            for piece in self._pat.findall(seg):
+                mapped = "".join(self._b2u[b] for b in piece.encode("utf-8"))
+                ids.extend(self.vocab.get(tok, self.EOS) for tok in self._bpe(mapped))
+        return ids
+
+    def __call__(self, prompts: List[str]) -> torch.Tensor:
+        out = torch.full((len(prompts), self.length), self.pad_id, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            ids = [self.BOS] + self.encode(p)[: self.length - 2] + [self.EOS]
+            out[i, : len(ids)] = torch.tensor(ids)
+        return out
+
+
 class ClipTextTower:
     """A CLIP text transformer on torch ops (``transformers`` architecture): the reference's
     ``text_encoder(tokens)[0]`` (SD1.5, latent_diffusion.py:105-113) or ``hidden_states[-2]`` + projected pooled
@@ -74,12 +173,16 @@ class ClipTextTower:
     ``encode(list[str]) -> (hidden [n,77,D] fp16, pooled [n,P] fp16 | None)`` like every text encoder here."""
 
     def __init__(self, hidden: int, layers: int, heads: int, intermediate: int, act: str, proj_dim: Optional[int],
-                 penultimate: bool, pad_id: Optional[int], device="cpu", dtype=torch.float32, weights=None, seed: int = 0):
+                 penultimate: bool, pad_id: Optional[int], device="cpu", dtype=torch.float32, weights=None, seed: int = 0,
+                 tokenizer=None):
+        """``tokenizer``: ``prompts -> LongTensor [n, 77]`` with ``BOS`` / ``EOS`` / ``VOCAB`` attributes - a
+        ``ClipBpeTokenizer`` built from a checkpoint's vocab.json / merges.txt; default: the vocabulary-free HashTokenizer."""
         from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
-        cfg = CLIPTextConfig(vocab_size=HashTokenizer.VOCAB, hidden_size=hidden, intermediate_size=intermediate,
+        tok = tokenizer if tokenizer is not None else HashTokenizer(pad_id)
+        cfg = CLIPTextConfig(vocab_size=tok.VOCAB, hidden_size=hidden, intermediate_size=intermediate,
                              num_hidden_layers=layers, num_attention_heads=heads, max_position_embeddings=77,
-                             hidden_act=act, projection_dim=proj_dim or hidden, bos_token_id=HashTokenizer.BOS,
-                             eos_token_id=HashTokenizer.EOS, pad_token_id=1)
+                             hidden_act=act, projection_dim=proj_dim or hidden, bos_token_id=tok.BOS,
+                             eos_token_id=tok.EOS, pad_token_id=1)
         torch.manual_seed(seed)
         self.model = (CLIPTextModelWithProjection(cfg) if proj_dim else CLIPTextModel(cfg)).eval()
         if weights is not None:
@@ -88,9 +191,34 @@ class ClipTextTower:
                 weights = dict(load_safetensors_iter(weights))
             self.model.load_state_dict(weights)
         self.model.to(device=device, dtype=dtype)
-        self.tok = HashTokenizer(pad_id)
+        self.tok = tok
         self.penultimate, self.proj = penultimate, bool(proj_dim)
         self.device = device
+
+    @classmethod
+    def from_dir(cls, encoder_dir, tokenizer_dir, penultimate: bool, with_projection: bool, pad_token: Optional[str] = None,
+                 device="cpu", dtype=torch.float32):
+        """A tower from a diffusers-layout checkpoint: ``encoder_dir`` holds ``config.json`` + ``model.safetensors`` (the
+        ``text_encoder`` / ``text_encoder_2`` subfolder), ``tokenizer_dir`` holds ``vocab.json`` + ``merges.txt`` (``tokenizer``
+        / ``tokenizer_2``).  SD1.5: ``penultimate=False, with_projection=False``; SDXL: tower 1 ``penultimate=True,
+        with_projection=False``, tower 2 ``penultimate=True, with_projection=True, pad_token="!"``
+        (reference latent_diffusion.py:92-113, latent_sdxl.py:56-93)."""
+        import os
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+        from .weights import load_safetensors_iter
+        self = cls.__new__(cls)
+        cfg = CLIPTextConfig.from_json_file(os.path.join(str(encoder_dir), "config.json"))
+        self.model = (CLIPTextModelWithProjection(cfg) if with_projection else CLIPTextModel(cfg)).eval()
+        sd = dict(load_safetensors_iter(os.path.join(str(encoder_dir), "model.safetensors")))
+        sd.pop("text_model.embeddings.position_ids", None)         # a buffer older checkpoints still carry
+        self.model.load_state_dict(sd)
+        self.model.to(device=device, dtype=dtype)
+        self.tok = ClipBpeTokenizer(os.path.join(str(tokenizer_dir), "vocab.json"), os.path.join(str(tokenizer_dir), "merges.txt"),
+                                    pad_token=pad_token)
+        if self.tok.VOCAB > cfg.vocab_size:
+            raise ValueError(f"tokenizer has {self.tok.VOCAB} ids but the encoder embeds only {cfg.vocab_size}")
+        self.penultimate, self.proj, self.device = penultimate, bool(with_projection), device
+        return self
 
     @classmethod
     def clip_l(cls, **kw):        # SD1.5 text encoder / SDXL text_encoder (12 layers, 768 wide)

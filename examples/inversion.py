@@ -35,7 +35,7 @@ REFERENCE_FLAGS = (
     ("img_size", int, 512), ("device", str, "cuda"), ("null_prompt", str, ""), ("prompt", str, ""),
     ("cfg_guidance", float, 7.5), ("method", str, "ddim_inversion_cfg++"), ("NFE", int, 10), ("seed", int, 42),
 )
-EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None))
+EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("model_dir", str, None))
 
 
 def main(argv=None, solver_kwargs=None) -> None:
@@ -56,6 +56,15 @@ def main(argv=None, solver_kwargs=None) -> None:
               unet_weights=args.unet_weights, latent_hw=(size // 8, size // 8))
     if args.vae_weights:
         kw["vae_weights"] = args.vae_weights
+    if args.model_dir:        # a local diffusers-layout checkpoint: UNet / VAE weights, CLIP tower(s) + BPE tokenizer(s)
+        from cfgpp_amd.checkpoint import solver_kwargs_from_dir
+        found, missing = solver_kwargs_from_dir(args.model_dir, args.model in ("sdxl", "sdxl_lightning"), args.device)
+        if missing:
+            print(f"--model_dir {args.model_dir}: no {', '.join(missing)} there - synthetic stand-in(s) used")
+        for k, v in found.items():
+            if k.endswith("_weights") and getattr(args, k, None) not in (None, "synthetic"):
+                continue                                   # an explicit --unet_weights / --vae_weights wins
+            kw[k] = v
     kw.update(solver_kwargs or {})
     if xl:
         from cfgpp_amd.latent_sdxl import get_solver

@@ -31,7 +31,7 @@ REFERENCE_FLAGS = (
     ("null_prompt", str, "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,"), ("prompt", str, ""),
     ("cfg_guidance", float, 7.5), ("method", str, "ddim"), ("NFE", int, 50), ("seed", int, 42),
 )
-EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("batch", int, 1))
+EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("model_dir", str, None), ("batch", int, 1))
 
 
 def main(argv=None, solver_kwargs=None) -> None:
@@ -51,6 +51,15 @@ def main(argv=None, solver_kwargs=None) -> None:
     kw = dict(solver_config=cfg, device=args.device, max_batch=args.batch, unet_weights=args.unet_weights)
     if args.vae_weights:
         kw["vae_weights"] = args.vae_weights
+    if args.model_dir:        # a local diffusers-layout checkpoint: UNet / VAE weights, CLIP tower(s) + BPE tokenizer(s)
+        from cfgpp_amd.checkpoint import solver_kwargs_from_dir
+        found, missing = solver_kwargs_from_dir(args.model_dir, args.model in ("sdxl", "sdxl_lightning"), args.device)
+        if missing:
+            print(f"--model_dir {args.model_dir}: no {', '.join(missing)} there - synthetic stand-in(s) used")
+        for k, v in found.items():
+            if k.endswith("_weights") and getattr(args, k, None) not in (None, "synthetic"):
+                continue                                   # an explicit --unet_weights / --vae_weights wins
+            kw[k] = v
     kw.update(solver_kwargs or {})
     prompts = [args.prompt] * args.batch if args.batch > 1 else args.prompt
     seeds = None if args.batch == 1 else [args.seed + i for i in range(args.batch)]   # B = 1: global CPU RNG, like the reference

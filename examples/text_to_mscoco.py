@@ -32,7 +32,7 @@ REFERENCE_FLAGS = (
     ("device", str, "cuda"), ("null_prompt", str, ""), ("prompt", str, ""), ("cfg_guidance", float, 7.5),
     ("method", str, "ddim"), ("NFE", int, 50), ("seed", int, 42),
 )
-EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("batch", int, 1), ("limit", int, 10000))
+EXTRA_FLAGS = (("unet_weights", str, "synthetic"), ("vae_weights", str, None), ("model_dir", str, None), ("batch", int, 1), ("limit", int, 10000))
 
 
 def read_captions(path: Path, limit: int = 10000) -> list:
@@ -66,6 +66,15 @@ def main(argv=None, solver_kwargs=None) -> int:
     kw = dict(solver_config=cfg, device=args.device, max_batch=B, unet_weights=args.unet_weights)
     if args.vae_weights:
         kw["vae_weights"] = args.vae_weights
+    if args.model_dir:        # a local diffusers-layout checkpoint: UNet / VAE weights, CLIP tower(s) + BPE tokenizer(s)
+        from cfgpp_amd.checkpoint import solver_kwargs_from_dir
+        found, missing = solver_kwargs_from_dir(args.model_dir, args.model in ("sdxl", "sdxl_lightning"), args.device)
+        if missing:
+            print(f"--model_dir {args.model_dir}: no {', '.join(missing)} there - synthetic stand-in(s) used")
+        for k, v in found.items():
+            if k.endswith("_weights") and getattr(args, k, None) not in (None, "synthetic"):
+                continue                                   # an explicit --unet_weights / --vae_weights wins
+            kw[k] = v
     kw.update(solver_kwargs or {})
     xl = args.model in ("sdxl", "sdxl_lightning")
     if xl:

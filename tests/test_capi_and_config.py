@@ -90,3 +90,113 @@ def test_clip_text_towers_shapes_and_determinism():
     g = ClipTextTower.open_clip_bigg(layers=2)
     h1, _ = l_pen(["a cat"]); h2, p2 = g(["a cat"])
     assert torch.cat([h1, h2], -1).shape == (1, 77, 2048) and p2.shape == (1, 1280)
+
+
+def _toy_clip_vocab(n_merges=120):
+    """a small CLIP-layout vocabulary: 256 byte characters, the same with </w>, merges learnt by plain BPE on a toy
+    corpus, then the two special tokens (the layout of the real 49 408-entry vocab.json / merges.txt)"""
+    import collections
+    from cfgpp_amd.conditioning import _bytes_to_unicode
+    b2u = _bytes_to_unicode()
+    corpus = ("a photo of a cat sitting on the sofa . two dogs playing in the park , photorealistic 4k "
+              "an astronaut riding a horse on mars ; it's the painter's best work ! low quality jpeg artifacts blurry "
+              "caf\u00e9 na\u00efve \u732b the cats' toys don't matter 1920s style ... ") * 3
+    words = collections.Counter()
+    import regex
+    for piece in regex.findall(r"'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", corpus.lower()):
+        mapped = [b2u[b] for b in piece.encode("utf-8")]
+        mapped[-1] += "</w>"
+        words[tuple(mapped)] += 1
+    merges = []
+    for _ in range(n_merges):
+        pairs = collections.Counter()
+        for w, c in words.items():
+            for a, b in zip(w[:-1], w[1:]):
+                pairs[(a, b)] += c
+        if not pairs:
+            break
+        best = max(sorted(pairs), key=lambda p: pairs[p])
+        merges.append(best)
+        new_words = collections.Counter()
+        for w, c in words.items():
+            out, i = [], 0
+            while i < len(w):
+                if i + 1 < len(w) and (w[i], w[i + 1]) == best:
+                    out.append(w[i] + w[i + 1]); i += 2
+                else:
+                    out.append(w[i]); i += 1
+            new_words[tuple(out)] += c
+        words = new_words
+    base = list(b2u.values())
+    tokens = base + [c + "</w>" for c in base] + ["".join(m) for m in merges] + ["<|startoftext|>", "<|endoftext|>"]
+    return {t: i for i, t in enumerate(tokens)}, merges
+
+
+def test_clip_bpe_tokenizer_matches_transformers(tmp_path):
+    """ClipBpeTokenizer (our restatement of CLIP's byte-level BPE) == transformers.CLIPTokenizer on the same vocabulary
+    files: ids, truncation to 77, EOS- and "!"-padding (the two SDXL tokenizers)."""
+    import json
+    import torch
+    from transformers import CLIPTokenizer
+    from cfgpp_amd.conditioning import ClipBpeTokenizer, ClipTextTower
+    vocab, merges = _toy_clip_vocab()
+    (tmp_path / "vocab.json").write_text(json.dumps(vocab, ensure_ascii=False), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n", encoding="utf-8")
+    ours = ClipBpeTokenizer(tmp_path / "vocab.json", tmp_path / "merges.txt")
+    ours_bang = ClipBpeTokenizer(vocab, [" ".join(m) for m in merges], pad_token="!")
+    ref = CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges])
+    ref_bang = CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges], pad_token="!")
+    prompts = ["a photo of a cat", "", "  Two   DOGS playing,\tin the park!!  ", "it's the painter's best work; don't", "1920s caf\u00e9 na\u00efve \u732b ...",
+               "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,", "an astronaut " * 60, "<|endoftext|> a cat <|startoftext|>",
+               "e\u0301 combining accent", "emoji \U0001f600 and symbols #$%&*"]
+    want = ref(prompts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    got = ours(prompts)
+    assert got.shape == (len(prompts), 77) and got.dtype == torch.long
+    for i, p in enumerate(prompts):
+        assert torch.equal(got[i], want[i]), (p, got[i].tolist()[:20], want[i].tolist()[:20])
+    want_bang = ref_bang(prompts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    assert torch.equal(ours_bang(prompts), want_bang)
+    assert got[0, 0] == ours.BOS and got[1, 1] == ours.EOS and got[6, 76] == ours.EOS          # empty prompt; truncated prompt ends with EOS
+    # plugs into the text tower: vocabulary size and EOS pooling position come from the tokenizer
+    tower = ClipTextTower.open_clip_bigg(layers=1, tokenizer=ours_bang)
+    hs, pooled = tower(["a photo of a cat", "two dogs"])
+    assert hs.shape == (2, 77, 1280) and pooled.shape == (2, 1280) and torch.isfinite(hs.float()).all()
+    assert tower.model.config.vocab_size == len(vocab)
+
+
+def test_clip_tower_from_checkpoint_directory(tmp_path):
+    """ClipTextTower.from_dir: config.json + model.safetensors + vocab.json + merges.txt of a (tiny) diffusers-layout text
+    encoder give exactly what transformers computes from the same files - last_hidden_state for SD1.5, hidden_states[-2] /
+    [-(clip_skip+2)] and the projected pooled output for the SDXL towers."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+    from cfgpp_amd.conditioning import ClipTextTower
+    vocab, merges = _toy_clip_vocab()
+    tok_dir = tmp_path / "tokenizer"; tok_dir.mkdir()
+    (tok_dir / "vocab.json").write_text(json.dumps(vocab, ensure_ascii=False), encoding="utf-8")
+    (tok_dir / "merges.txt").write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n", encoding="utf-8")
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                         max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=48,
+                         bos_token_id=vocab["<|startoftext|>"], eos_token_id=vocab["<|endoftext|>"], pad_token_id=1)
+    prompts = ["a photo of a cat", "two dogs playing in the park!"]
+    for proj, pad in ((False, None), (True, "!")):
+        torch.manual_seed(5)
+        ref = (CLIPTextModelWithProjection(cfg) if proj else CLIPTextModel(cfg)).eval()
+        enc_dir = tmp_path / f"text_encoder_{int(proj)}"; enc_dir.mkdir()
+        cfg.to_json_file(str(enc_dir / "config.json"))
+        save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, str(enc_dir / "model.safetensors"))
+        ids = CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges], **({"pad_token": pad} if pad else {}))(
+            prompts, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        with torch.no_grad():
+            out = ref(input_ids=ids, output_hidden_states=True)
+        sd15 = ClipTextTower.from_dir(enc_dir, tok_dir, penultimate=False, with_projection=proj, pad_token=pad)
+        xl = ClipTextTower.from_dir(enc_dir, tok_dir, penultimate=True, with_projection=proj, pad_token=pad)
+        hs, pooled = sd15(prompts)
+        assert torch.equal(hs, out.last_hidden_state.half()) and (pooled is None) == (not proj)
+        hs2, pooled2 = xl(prompts)
+        assert torch.equal(hs2, out.hidden_states[-2].half())
+        assert torch.equal(xl(prompts, clip_skip=1)[0], out.hidden_states[-3].half())
+        if proj:
+            assert torch.equal(pooled2, out.text_embeds.half())

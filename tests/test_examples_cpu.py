@@ -96,3 +96,50 @@ def test_solver_with_clip_text_tower():
     img = s.sample(prompt=["", "a cat"], cfg_guidance=0.6)
     assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
     assert eng.ehs.shape == (2, 77, 768) and eng.ehs.dtype == torch.float16
+
+
+def _tiny_checkpoint_dir(root, sdxl=False):
+    """diffusers-layout directory with tiny CLIP text encoder(s) + toy BPE vocabulary (no unet / vae)"""
+    import json
+    from safetensors.torch import save_file
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from test_capi_and_config import _toy_clip_vocab
+    vocab, merges = _toy_clip_vocab()
+    towers = [("text_encoder", "tokenizer", False, 48)] + ([("text_encoder_2", "tokenizer_2", True, 80)] if sdxl else [])
+    for enc, tok, proj, hidden in towers:
+        (root / enc).mkdir(parents=True); (root / tok).mkdir(parents=True)
+        (root / tok / "vocab.json").write_text(json.dumps(vocab, ensure_ascii=False), encoding="utf-8")
+        (root / tok / "merges.txt").write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n", encoding="utf-8")
+        cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=2,
+                             num_attention_heads=4, max_position_embeddings=77, projection_dim=32,
+                             bos_token_id=vocab["<|startoftext|>"], eos_token_id=vocab["<|endoftext|>"], pad_token_id=1)
+        torch.manual_seed(11)
+        model = (CLIPTextModelWithProjection(cfg) if proj else CLIPTextModel(cfg)).eval()
+        cfg.to_json_file(str(root / enc / "config.json"))
+        save_file({k: v.contiguous() for k, v in model.state_dict().items()}, str(root / enc / "model.safetensors"))
+    return root
+
+
+def test_model_dir_flag_plugs_real_text_path(tmp_path, capsys):
+    """--model_dir: CLIP tower + BPE tokenizer from a diffusers-layout directory replace the synthetic text encoder;
+    absent unet / vae folders are reported and the synthetic stand-ins stay"""
+    import text_to_img
+    from cfgpp_amd.checkpoint import solver_kwargs_from_dir
+    from cfgpp_amd.conditioning import ClipTextTower
+    ckpt = _tiny_checkpoint_dir(tmp_path / "sd15_ckpt")
+    found, missing = solver_kwargs_from_dir(ckpt, sdxl=False, device="cpu")
+    assert missing == ["unet", "vae"] and isinstance(found["text_encoder"], ClipTextTower)
+    eng = MockEngine(_unet, (8, 8))
+    text_to_img.main(["--method", "ddim_cfg++", "--cfg_guidance", "0.6", "--NFE", "2", "--prompt", "a photo of a cat", "--device", "cpu",
+                      "--model_dir", str(ckpt), "--workdir", str(tmp_path / "out")], solver_kwargs=dict(engine=eng, vae=StubVAE(0.18215), latent_hw=(8, 8)))
+    assert "no unet, vae there" in capsys.readouterr().out
+    assert eng.ehs.shape == (2, 77, 48) and eng.ehs.dtype == torch.float16        # the tiny tower's width, not the synthetic 768
+    want = found["text_encoder"](["a photo of a cat"])[0]
+    assert torch.equal(eng.ehs[1:2].cpu(), want)
+    # SDXL: two towers, concatenated hidden states, pooled from the projected second tower
+    xl = _tiny_checkpoint_dir(tmp_path / "xl_ckpt", sdxl=True)
+    found, missing = solver_kwargs_from_dir(xl, sdxl=True, device="cpu")
+    t1, t2 = found["text_encoder"]
+    assert t1.penultimate and t2.penultimate and t2.proj and not t1.proj and t2.tok.pad_id == t2.tok.vocab["!"]
+    h1, _ = t1(["a cat"]); h2, p2 = t2(["a cat"])
+    assert torch.cat([h1, h2], -1).shape == (1, 77, 128) and p2.shape == (1, 32)
