@@ -64,6 +64,7 @@ PROTOTYPES = {
     "cfgpp_vae_decode": (_I, [_P, _P, _P, _I, _P]),
     "cfgpp_vae_decode_image": (_I, [_P, _P, _P, _I, _P]),
     "cfgpp_vae_encode": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "cfgpp_vae_profile": (_I, [_P, _P, _P, _I, _P, C.c_char_p, C.c_long]),
     "cfgpp_vae_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_encode_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_device_bytes": (C.c_double, [_P]),

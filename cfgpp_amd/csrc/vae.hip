@@ -393,6 +393,36 @@ int cfgpp_vae_encode(cfgpp_vae* v, const void* img, const void* noise, void* z, 
     return 0;
 }
 
+// One decode with a HIP event between every launch of the decoder plan (the VAE's twin of cfgpp_unet_profile): one line per
+// launch in `detail` - index, family (0 igemm, 1 attention GEMMs, 2 norm / softmax, 3 small), description, us, GFLOP.
+int cfgpp_vae_profile(cfgpp_vae* v, const void* z, void* img, int B, void* stream, char* detail, long detail_cap) {
+    CFGPP_REQUIRE(v && v->finalized && z && img && detail && detail_cap > 0 && B > 0 && B <= v->max_rows, "vae_profile: bad args");
+    v->in_z = z; v->out_img = img; v->post_scale = 0.5f; v->post_shift = 0.5f; v->post_clamp = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (v->tuned_rows != B && igemm_autotune_enabled()) { int e = v->tune_plan(s, B); if (e) return e; }
+    const size_t n = v->plan.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) CFGPP_HIP_CHECK(hipEventCreate(&e));
+    CFGPP_HIP_CHECK(hipEventRecord(ev[0], s));
+    int rc = 0;
+    for (size_t i = 0; i < n && rc == 0; ++i) { rc = v->plan[i](s, B); if (rc == 0 && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = -1; }
+    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = -1;
+    if (rc == 0) {
+        std::string txt;
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f; hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            char line[256];
+            snprintf(line, sizeof(line), "%zu\t%d\t%s\t%.1f\t%.3f\n", i, v->plan_kind[i], v->plan_desc[i].c_str(), ms * 1e3,
+                     2.0 * v->plan_macs[i] * B * 1e-9);
+            txt += line;
+        }
+        const long ncopy = std::min<long>((long)txt.size(), detail_cap - 1);
+        std::memcpy(detail, txt.data(), ncopy); detail[ncopy] = 0;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
 double cfgpp_vae_flops(cfgpp_vae* v, int B) { return v && v->finalized ? 2.0 * v->dec_macs * B : 0.0; }
 double cfgpp_vae_encode_flops(cfgpp_vae* v, int B) { return v && v->finalized ? 2.0 * v->enc_macs * B : 0.0; }
 double cfgpp_vae_device_bytes(cfgpp_vae* v) { return v ? v->dev_bytes : 0.0; }

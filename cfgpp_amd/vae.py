@@ -160,6 +160,21 @@ class HipVAE:
             self.lib.cfgpp_vae_destroy(h)
             self._h = None
 
+    def profile(self, zt: torch.Tensor) -> list:
+        """one decode with HIP events between the launches: [(family, description, us, GFLOP)] in plan order"""
+        import ctypes as C
+        from ._lib import check
+        zt = zt.to(self.device, torch.float32).contiguous()
+        img = torch.empty((zt.shape[0], 3, 8 * self.h, 8 * self.w), dtype=torch.float32, device=self.device)
+        buf = C.create_string_buffer(1 << 20)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.cfgpp_vae_profile(self._h, zt.data_ptr(), img.data_ptr(), int(zt.shape[0]), stream, buf, 1 << 20), "cfgpp_vae_profile")
+        rows = []
+        for line in buf.value.decode().strip().split("\n"):
+            _, kind, desc, us, gf = line.split("\t")
+            rows.append((int(kind), desc, float(us), float(gf)))
+        return rows
+
     def decode_image(self, zt: torch.Tensor) -> torch.Tensor:
         """zt -> ``(decode(zt) / 2 + 0.5).clamp(0, 1)`` with the post-processing of the solvers' ``sample()`` folded into
         the decoder's last kernel (latent_diffusion.py:676-677)."""
@@ -194,7 +209,7 @@ class HipVAE:
         z = torch.empty((B, 4, self.h, self.w), dtype=torch.float32, device=self.device)
         mom = torch.empty((B, 8, self.h, self.w), dtype=torch.float32, device=self.device) if return_moments else None
         check(self.lib.cfgpp_vae_encode(self._h, img.data_ptr(), None if nz is None else nz.data_ptr(), z.data_ptr(),
-                                        None if mom is None else mom.data_ptr(), B, torch.cuda.current_stream().cuda_stream),
+                                        None if mom is None else mom.data_ptr(), B, torch.cuda.current_stream(self.device).cuda_stream),
               "cfgpp_vae_encode")
         return (z, mom) if return_moments else z
 

@@ -156,6 +156,9 @@ int cfgpp_vae_decode_image(cfgpp_vae* v, const void* z, void* img, int B, void* 
  * img [B][3][8h][8w] f32, noise [B][4][h][w] f32 or NULL (posterior mean), z [B][4][h][w] f32,
  * moments [B][8][h][w] f32 or NULL (mean | logvar clamped to [-30, 20]). */
 int cfgpp_vae_encode(cfgpp_vae* v, const void* img, const void* noise, void* z, void* moments, int B, void* stream);
+/* one decode (image post-processing included) with a HIP event between every launch of the decoder plan; `detail` receives one
+ * line per launch: index \t family (0 igemm, 1 attention GEMMs, 2 norm / softmax, 3 small) \t description \t us \t GFLOP */
+int cfgpp_vae_profile(cfgpp_vae* v, const void* z, void* img, int B, void* stream, char* detail, long detail_cap);
 double cfgpp_vae_flops(cfgpp_vae* v, int B);
 double cfgpp_vae_encode_flops(cfgpp_vae* v, int B);
 double cfgpp_vae_device_bytes(cfgpp_vae* v);
