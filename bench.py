@@ -236,7 +236,8 @@ def roofline_block(eng, config, B, dev, rnd):
                         "note": "algorithmic bytes (GroupNorm / LayerNorm 4 B per element, step 16 B per latent element) / HIP-event time; "
                                 "the step kernel moves %.0f KB per launch and is launch-latency bound" % (16.0 * zz.numel() / 1e3),
                         "peak": 8000.0},
-           "pmc_source": None if pmc is None else os.path.relpath(pf, ROOT)}
+           "pmc_source": None if pmc is None else os.path.relpath(pf, ROOT),
+           "pmc_note": None if pmc is None else pmc.get("note")}
     return out
 
 
