@@ -1229,6 +1229,8 @@ static int g_split_cfg = 14;
 extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
 static int g_mf16 = 4;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
 extern "C" void cfgpp_igemm_set_mf16(int mode) { g_mf16 = (mode == 3 || mode == 4) ? mode : 0; }
+static int g_mf16_rounds = 1;          // the rule also takes grids of exactly 2 .. n full rounds of 256 tiles (1 = one round only)
+extern "C" void cfgpp_igemm_set_mf16_rounds(int n) { g_mf16_rounds = n >= 1 ? n : 1; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
 // big-tile K-split rule: least K-tiles per slice (0 = rule off, the default: inside a forward the 3-stage 256 x 128 tile the
@@ -1297,7 +1299,9 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     // to_out K = 1280 436 -> 505, SD1.5 forward 21.06 -> 20.61 ms (profiles/r02/ab/igemm_mf16_run9.txt).
     if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a)) {
         const long t7 = (long)cdiv(a.M, 128) * (a.N / 160);
-        if (t7 >= 200 && t7 <= 256) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
+        // (g_mf16_rounds > 1: also grids of exactly 2 .. g_mf16_rounds full rounds - an A/B knob, default 1)
+        const bool full_rounds = t7 > 256 && t7 % 256 == 0 && t7 / 256 <= g_mf16_rounds;
+        if ((t7 >= 200 && t7 <= 256) || full_rounds) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
     }
     if (g_force_cfg == 0 && a.cfg_hint > 0 && g_staging != 0 && !big_split) {
         const int KT = a.K >> 6;
