@@ -94,6 +94,7 @@ PROTOTYPES = {
     "cfgpp_igemm_set_split_tile": (None, [_I]),
     "cfgpp_igemm_set_mf16": (None, [_I]),
     "cfgpp_igemm_set_mf16_rounds": (None, [_I]),
+    "cfgpp_igemm_set_mf16_heads": (None, [_I]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
     "cfgpp_groupnorm_set_mode": (None, [_I]),

@@ -811,7 +811,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 //     16-lane groups of a ds_read_b128 hit 16 distinct bank quads (same argument as the 32-row case);
 //   * 8 waves x 8 rows = 64 rows per loader pass: 128 activation rows = 2 passes, 160 weight rows = 2 passes + one that
 //     only waves 0-3 take, so the counted vmcnt waits use the WAVE's piece count (5 or 4 per K-tile);
-//   * plain-store epilogue only (bias / temb / residual through the per-wave LDS transpose); whole tiles only (no K-split).
+//   * plain-store epilogue (bias / temb / residual through the per-wave LDS transpose) and a head-major one (switched off until
+//     it has run on hardware: cfgpp_igemm_set_mf16_heads); whole tiles only (no K-split).
 // The 16 x 16 x 32 MFMA sums k in a different order than the 32 x 32 x 16 one, so this tile is NOT a tuner candidate (the
 // tuner's choices must not change results): it is used by rule (igemm_launch; cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
 __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
@@ -870,6 +871,72 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
                 for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
             }
             *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
+        }
+    }
+}
+
+// EPI_HEADS for the 16 x 16 accumulator layout: the wave's 32-token x 80-column slab goes through LDS as five
+// 32-token x 16-column blocks - row-major [token][column] (48-byte pitch) for Q / K columns, transposed
+// [head dim][key position] (80-byte pitch, positions in the attention kernel's permuted order unless vt_linear) for V
+// columns - and leaves as 16-byte pieces: 8 head dims of one token, or 8 key positions of one head dim.
+// Needs rows_per_batch % 32 == 0, part_width % 16 == 0, head_dim % 8 == 0 (checked by mf16_supports).
+__device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
+                                                              char* stg /* wave-private, 5 * 1536 bytes */) {
+    constexpr int BLK = 1536, QK_PITCH = 48, VT_PITCH = 80;
+    if (mw0 >= p.M) return;
+    const int c16 = lane & 15, fq = lane >> 4;
+    const int HW = p.rows_per_batch;
+    const int b = mw0 / HW, tok0 = mw0 - b * HW;               // one batch, one aligned 32-token block
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int ng = nw0 + j * 16;                           // first column of the 16-column group (ng < N: N % 160 == 0)
+        const int part = ng / p.part_width + p.part0;
+        char* blk = stg + j * BLK;
+        const int n = ng + 4 * fq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = i * 16 + c16;                        // token row inside the 32-token block
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
+            if (p.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (part == 2) {
+                const int pos = p.vt_linear ? r : cfgpp_vt_pos(r);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<half_t*>(blk + (4 * fq + k) * VT_PITCH + pos * 2) = (half_t)v[k];
+            } else {
+                half4_t o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
+                *reinterpret_cast<half4_t*>(blk + r * QK_PITCH + (4 * fq) * 2) = o;
+            }
+        }
+    }
+    // 64 pieces of 16 bytes per group: one per lane
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int ng = nw0 + j * 16;
+        const int part = ng / p.part_width + p.part0;
+        const char* blk = stg + j * BLK;
+        if (part == 2) {                                       // row = head-dim column ng + r, piece = 8 key positions
+            const int r = lane >> 2, c4 = lane & 3;
+            const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * VT_PITCH + c4 * 16);
+            const int cn = (ng + r) % p.part_width;
+            const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+            const long bh = (long)b * p.heads + head;
+            *reinterpret_cast<half8_t*>(p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok0 + 8 * c4) = v;
+        } else {                                               // row = token tok0 + r, piece = 8 head dims
+            const int r = lane >> 1, c2 = lane & 1;
+            const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * QK_PITCH + c2 * 16);
+            const int cn = (ng + 8 * c2) % p.part_width;
+            const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+            const long bh = (long)b * p.heads + head;
+            half_t* base = part == 0 ? p.hq : p.hk;
+            const int tp = part == 0 ? p.q_tok_pad : p.tok_pad;
+            *reinterpret_cast<half8_t*>(base + (bh * tp + tok0 + r) * p.head_dim_pad + dd) = v;
         }
     }
 }
@@ -1057,7 +1124,8 @@ igemm16_kernel(const IGemmArgs p) {
 #undef CFGPP_WAIT_TILES
 
     // the k-loop ended with vmcnt(0) + barrier: LDS is free for the per-wave transposes
-    igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
+    if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536));
+    else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
 }
 
 // ---- launch + tail scheduling ------------------------------------------------------------------
@@ -1138,8 +1206,13 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
 // forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
 // variant of the same tile (the LDS-DMA variant is the default)
 // 128 x 160 tile on 8 waves of 16x16x32 MFMAs (igemm16_kernel): whole tiles, plain-store epilogue
+static int g_mf16_heads = 0;           // 1: EPI_HEADS launches may use the tile too (head-major epilogue for the 16 x 16 layout)
+extern "C" void cfgpp_igemm_set_mf16_heads(int on) { g_mf16_heads = on ? 1 : 0; }
 static bool mf16_supports(const IGemmArgs& a) {
-    return a.epi == EPI_STORE && a.N % 160 == 0 && g_staged_epi && a.K >= 64;
+    if (a.N % 160 != 0 || !g_staged_epi || a.K < 64) return false;
+    if (a.epi == EPI_STORE) return true;
+    return a.epi == EPI_HEADS && g_mf16_heads && a.rows_per_batch % 32 == 0 && a.M % 32 == 0 && a.part_width % 16 == 0 &&
+           a.head_dim % 8 == 0;
 }
 template <int AMODE, int NST>
 int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {

@@ -229,6 +229,8 @@ void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K 
 /* 8-wave 16x16x32-MFMA 128x160 tile for plain-store launches whose 128x160 grid is 200..256 tiles: 0 = off, 3 / 4 (default 4) =
  * on with that many LDS stages.  Rule-based (the tile sums k in a different order than the others, so the tuner never picks it). */
 void cfgpp_igemm_set_mf16(int mode);
+/* 1: QKV / Q / KV projections (head-major epilogue) may use that tile too; default 0 until validated on hardware */
+void cfgpp_igemm_set_mf16_heads(int on);
 /* A/B knob of that rule: also take grids of exactly 2 .. n full rounds of 256 tiles (default 1 = one round only) */
 void cfgpp_igemm_set_mf16_rounds(int n);
 /* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */

@@ -310,6 +310,33 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     return out
 
 
+@case("heads_projection_d40")
+def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
+    """QKV projection at the SD1.5 level-0 geometry (N = 960 = 6 x 160, head dim 40: 16-column groups straddle heads): the
+    heuristic tile and the 4-wave 128x160 tile; with CFGPP_TEST_MF16_HEADS=1 also the 16x16x32-MFMA tile's head-major
+    epilogue (configs 18 / 19, switched off by default until it has run on hardware)."""
+    import os
+    a = rnd(B * tokens, C, seed=46)
+    w = rnd(3 * C, C, scale=C ** -0.5, seed=47)
+    d = C // nheads
+    qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
+    y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
+    cfgs = [0, 7] + ([18, 19] if os.environ.get("CFGPP_TEST_MF16_HEADS") == "1" else [])
+    out = {}
+    H.lib().cfgpp_igemm_set_mf16_heads(1 if 18 in cfgs else 0)
+    try:
+        for c in cfgs:
+            H.lib().cfgpp_igemm_force_config(c)
+            hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
+            out[f"q_cfg{c}"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+            out[f"k_cfg{c}"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
+            out[f"vt_cfg{c}"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+    finally:
+        H.lib().cfgpp_igemm_force_config(0)
+        H.lib().cfgpp_igemm_set_mf16_heads(0)
+    return out
+
+
 @case("conv_in_out")
 def t_cio():
     out = {}

@@ -98,6 +98,10 @@ def test_heads_projection_scatter(diag):
             assert r[k + sfx]["rel_l2"] < REL, (k, sfx, r[k + sfx])
 
 
+def test_heads_projection_head_dim_40(diag):
+    _check(diag, diag.t_heads_d40, "heads_projection_d40")
+
+
 def test_conv_in_out(diag):
     _check(diag, diag.t_cio, "conv_in_out")
 
