@@ -98,7 +98,12 @@ def test_heads_projection_scatter(diag):
             assert r[k + sfx]["rel_l2"] < REL, (k, sfx, r[k + sfx])
 
 
-def test_heads_projection_head_dim_40(diag):
+def test_heads_projection_head_dim_40_on_the_16x16x32_tile(diag):
+    """opt-in (CFGPP_TEST_MF16_HEADS=1): the head-major epilogue of igemm16_kernel is switched off and has not run on
+    hardware yet - this is its first-contact test (heuristic and 4-wave tiles at the same geometry as controls)"""
+    import os
+    if os.environ.get("CFGPP_TEST_MF16_HEADS") != "1":
+        pytest.skip("set CFGPP_TEST_MF16_HEADS=1 (unvalidated, switched-off code path)")
     _check(diag, diag.t_heads_d40, "heads_projection_d40")
 
 
