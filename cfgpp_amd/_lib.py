@@ -66,6 +66,12 @@ PROTOTYPES = {
     "cfgpp_vae_encode": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "cfgpp_vae_profile": (_I, [_P, _P, _P, _I, _P, C.c_char_p, C.c_long]),
     "cfgpp_vae_flops": (C.c_double, [_P, _I]),
+    "cfgpp_text_create": (_P, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "cfgpp_text_destroy": (None, [_P]),
+    "cfgpp_text_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_long), _I]),
+    "cfgpp_text_finalize": (_I, [_P]),
+    "cfgpp_text_encode": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _P, _P, _P]),
+    "cfgpp_text_device_bytes": (C.c_double, [_P]),
     "cfgpp_vae_encode_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_device_bytes": (C.c_double, [_P]),
     "cfgpp_op_softmax_rows": (_I, [_P, _L, _I, _P]),

@@ -23,6 +23,7 @@ SOURCES = [
     ("attn_kernel.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # scores are consumed by VALU: keep MFMA results in VGPRs
     ("unet.hip", []),
     ("vae.hip", []),
+    ("text.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -163,6 +163,27 @@ double cfgpp_vae_flops(cfgpp_vae* v, int B);
 double cfgpp_vae_encode_flops(cfgpp_vae* v, int B);
 double cfgpp_vae_device_bytes(cfgpp_vae* v);
 
+/* ---- CLIP text transformer -------------------------------------------------------------------------
+ * Replaces `self.text_encoder(tokens)` of the reference (latent_diffusion.py:105-113: last_hidden_state;
+ * latent_sdxl.py:76-93: hidden_states[-2] / [-(clip_skip+2)] and the second tower's projected pooled output).  Once per
+ * prompt, off the per-step path.  Geometry: hidden = heads * 64 (CLIP-L 768 / 12, OpenCLIP-bigG 1280 / 20), 77 tokens,
+ * act 0 = quick_gelu, 1 = gelu, proj_dim 0 = no text_projection.  Keys of cfgpp_text_load_tensor = the `transformers`
+ * CLIPTextModel(WithProjection) state dict ("text_model.embeddings.token_embedding.weight", ...,
+ * "text_model.encoder.layers.<i>.self_attn.q_proj.weight", ..., "text_model.final_layer_norm.bias", "text_projection.weight").
+ * First contact with hardware: tests/test_gpu_text.py (opt-in); nothing on the default path calls these yet. */
+typedef struct cfgpp_text cfgpp_text;
+cfgpp_text* cfgpp_text_create(int vocab, int hidden, int layers, int heads, int intermediate, int act, int proj_dim,
+                              int max_batch, int device_id);
+void cfgpp_text_destroy(cfgpp_text* t);
+int cfgpp_text_load_tensor(cfgpp_text* t, const char* key, const void* host, int dtype, const long* shape, int ndim);
+int cfgpp_text_finalize(cfgpp_text* t);
+/* ids: HOST int32 [B][77]; eos_pos: HOST int32 [B] (row that is pooled) or NULL; layer: -1 = last_hidden_state (final
+ * LayerNorm applied), k in [0, layers] = hidden_states[k]; hidden_out: DEVICE fp16 [B][77][hidden]; pooled_out: DEVICE fp32
+ * [B][proj_dim] or NULL. */
+int cfgpp_text_encode(cfgpp_text* t, const int* ids, const int* eos_pos, int B, int layer, void* hidden_out, float* pooled_out,
+                      void* stream);
+double cfgpp_text_device_bytes(cfgpp_text* t);
+
 /* ---- single ops, exposed for parity tests and micro-benchmarks ------------- */
 int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream);
 int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w, const float* bias,
