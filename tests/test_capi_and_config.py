@@ -200,3 +200,27 @@ def test_clip_tower_from_checkpoint_directory(tmp_path):
         assert torch.equal(xl(prompts, clip_skip=1)[0], out.hidden_states[-3].half())
         if proj:
             assert torch.equal(pooled2, out.text_embeds.half())
+
+
+def test_clip_bpe_tokenizer_fuzz_vs_transformers():
+    """seeded random strings over letters, digits, punctuation, whitespace kinds, accents, CJK, emoji, contractions and
+    in-text special tokens: both padding conventions must agree with transformers id for id"""
+    import random
+    import torch
+    from transformers import CLIPTokenizer
+    from cfgpp_amd.conditioning import ClipBpeTokenizer
+    vocab, merges = _toy_clip_vocab()
+    pairs = [(ClipBpeTokenizer(vocab, [" ".join(m) for m in merges]), CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges])),
+             (ClipBpeTokenizer(vocab, [" ".join(m) for m in merges], pad_token="!"),
+              CLIPTokenizer(vocab=vocab, merges=[tuple(m) for m in merges], pad_token="!"))]
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCDEFG0123456789 \t\n.,;:!?'\"-_()[]{}<>|/\\@#$%^&*+=~`") + [
+        "\u00e9", "\u00ef", "\u00df", "\u03a9", "\u732b", "\u72ac", "\U0001f600", "\u0301", "\u00a0", "\u200b", "\u2019", "\u201c", "\u2026",
+        "'s", "'t", "'re", "'ll", "n't", "<|endoftext|>", "<|startoftext|>", "  ", "!!"]
+    rng = random.Random(20260926)
+    strings = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 48))) for _ in range(500)]
+    strings += ["".join(rng.choice(alphabet) for _ in range(400)) for _ in range(20)]            # longer than 77 tokens: truncation
+    for ours, ref in pairs:
+        want = ref(strings, padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        got = ours(strings)
+        bad = [i for i in range(len(strings)) if not torch.equal(got[i], want[i])]
+        assert not bad, (repr(strings[bad[0]]), got[bad[0]].tolist()[:16], want[bad[0]].tolist()[:16])
