@@ -37,6 +37,16 @@ __device__ __forceinline__ float cfg_mix_f(float uc, float c, float lam) {
     return __fadd_rn(uc, __fmul_rn(__fsub_rn(c, uc), lam));
 }
 
+// `x / c` as the reference's backend evaluates it.  c > 0: IEEE division (torch-CPU, and every tensor / tensor division).
+// c < 0: the host passes c = -fl32(1 / divisor) and the kernel MULTIPLIES by -c: torch's GPU `div` with a CPU 0-dim
+// scalar (or python number) divisor - which is what `/ at.sqrt()`, `/ sigma.item()`, `/ (2*r)` and `/ (sigma**2+1)**0.5`
+// are in the reference - computes `a * (1/b)` with the reciprocal taken once on the host in fp32
+// (ATen BinaryDivTrueKernel.cu, `iter.is_cpu_scalar(2)`): up to 1 ulp away from the true quotient.  Every divisor on
+// this path is positive, so the sign is free to carry the choice (cfgpp_amd/coeffs.py: `divisor()`).
+__device__ __forceinline__ float div_as_ref(float x, float c) {
+    return c < 0.f ? __fmul_rn(x, -c) : __fdiv_rn(x, c);
+}
+
 template <bool EPS_HALF>
 __global__ void __launch_bounds__(256)
 ddim_step_kernel(float* __restrict__ z, float* __restrict__ z0t_out,
@@ -69,7 +79,7 @@ ddim_step_kernel(float* __restrict__ z, float* __restrict__ z0t_out,
             float pa = __fmul_rn(A, c1);
             float pb = __fmul_rn(B, c4);
             if (EPS_HALF) { pa = h_round(pa); pb = h_round(pb); }
-            z0[k] = __fdiv_rn(__fsub_rn(zi[k], pa), c2);
+            z0[k] = div_as_ref(__fsub_rn(zi[k], pa), c2);
             zn[k] = __fadd_rn(__fmul_rn(c3, z0[k]), pb);
         }
         reinterpret_cast<float4*>(z0t_out)[i] = make_float4(z0[0], z0[1], z0[2], z0[3]);
@@ -101,7 +111,7 @@ ddim_step_h_kernel(half_t* __restrict__ z, half_t* __restrict__ z0t_out,
             const float B = renoise_uc ? uc : hat;
             const float pa = h_round(__fmul_rn(A, c1));
             const float pb = h_round(__fmul_rn(B, c4));
-            const float z0f = h_round(__fdiv_rn(h_round(__fsub_rn((float)zv[k], pa)), c2));
+            const float z0f = h_round(div_as_ref(h_round(__fsub_rn((float)zv[k], pa)), c2));
             const float znf = h_round(__fadd_rn(h_round(__fmul_rn(c3, z0f)), pb));
             z0[k] = (half_t)z0f; zn[k] = (half_t)znf;
         }
@@ -110,14 +120,14 @@ ddim_step_h_kernel(half_t* __restrict__ z, half_t* __restrict__ z0t_out,
     }
 }
 
-// scale the k-diffusion latent into the UNet input: xc = x / s (SD1.5, mode 0) or x * s (SDXL 2M, mode 1)
+// scale the k-diffusion latent into the UNet input: xc = x / s (SD1.5, mode 0; s < 0: div_as_ref) or x * s (SDXL 2M, mode 1)
 __global__ void __launch_bounds__(256)
 kdiff_input_kernel(const half_t* __restrict__ x, half_t* __restrict__ xc, float s, int mode, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         float v = (float)x[i];
-        v = mode == 0 ? __fdiv_rn(v, s) : __fmul_rn(v, s);
+        v = mode == 0 ? div_as_ref(v, s) : __fmul_rn(v, s);
         xc[i] = (half_t)h_round(v);
     }
 }
@@ -126,11 +136,11 @@ struct KdiffCoef {
     float lam;
     float sigma;        // denoised (SD form):  x - h(eps*sigma)
     float c_out_h;      // denoised (XL form):  x + h(eps*c_out_h), c_out_h = fp16-rounded(-sigma)
-    float sigma_item;   // to_d: (x - d_from)/sigma_item
+    float sigma_item;   // to_d: (x - d_from)/sigma_item   (< 0: -1/sigma, see div_as_ref)
     float sigma_next;   // euler: den + d*sigma_next
     float neg_exp_mh_h; // fp16-rounded(-exp(-h))
     float expm1_mh_h;   // fp16-rounded(expm1(-h))
-    float two_r;        // 2*r (fp32)
+    float two_r;        // 2*r (fp32; < 0: -1/(2r), see div_as_ref)
     float exp_mh_h;     // fp16-rounded(exp(-h))
 };
 
@@ -160,7 +170,7 @@ kdiff_step_kernel(half_t* __restrict__ x, half_t* __restrict__ den_out, half_t* 
         const float d_from = variant == 0 ? den : uden;
         float xn;
         if (euler_branch) {
-            float d = h_round(__fdiv_rn(h_round(__fsub_rn(xv, d_from)), k.sigma_item));
+            float d = h_round(div_as_ref(h_round(__fsub_rn(xv, d_from)), k.sigma_item));
             xn = h_round(__fadd_rn(den, h_round(__fmul_rn(d, k.sigma_next))));
         } else {
             const float ov = (float)old[i];
@@ -168,7 +178,7 @@ kdiff_step_kernel(half_t* __restrict__ x, half_t* __restrict__ den_out, half_t* 
             const float diff_a = variant == 2 ? uden : den;
             float term1 = h_round(__fmul_rn(lead, k.neg_exp_mh_h));
             float t2 = h_round(__fmul_rn(h_round(__fsub_rn(diff_a, ov)), k.expm1_mh_h));
-            t2 = h_round(__fdiv_rn(t2, k.two_r));
+            t2 = h_round(div_as_ref(t2, k.two_r));
             float extra1 = h_round(__fsub_rn(term1, t2));
             float extra2 = h_round(__fmul_rn(xv, k.exp_mh_h));
             xn = h_round(__fadd_rn(h_round(__fadd_rn(den, extra1)), extra2));

@@ -205,9 +205,9 @@ class StableDiffusion:
         return x - model_pred * sigma
 
     # ------------------------------------------------------------------ fused loops
-    def _ddim_update(self, zt, z0t, noise_uc, noise_c, lam, sqrt4, tweedie_uc, renoise_uc):
+    def _ddim_update(self, zt, z0t, noise_uc, noise_c, lam, sqrt4, tweedie_uc, renoise_uc, device_alpha=None):
         co = K.ddim_coeffs_pinned(sqrt4, eps_half=(noise_uc.dtype == torch.float16), semantics=self.scalar_semantics,
-                                  z_half=(zt.dtype == torch.float16))
+                                  z_half=(zt.dtype == torch.float16), device_alpha=device_alpha)
         self.engine.step_ddim(zt, z0t, noise_uc, noise_c, lam, co, tweedie_uc, renoise_uc)
 
     def _own_latent(self, z):
@@ -236,7 +236,9 @@ class StableDiffusion:
             # unguarded (quirk Q3, wrap_index).  sqrt(at) etc. come from the pinned tables.
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, wrap=wrap_index)
             noise_uc, noise_c = self.predict_noise(zt, t, uc, c)
-            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, False, cfgpp)
+            # alpha(t - skip) of the last step is `final_alpha_cumprod.to(device)`: a DEVICE scalar (coeffs.py)
+            dev_a = "rn" if (not wrap_index and int(t) - self.tables.skip < 0) else None
+            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, False, cfgpp, dev_a)
             if callback_fn is not None:
                 self._run_callback(callback_fn, step, t, z0t, zt)
         return z0t, zt
@@ -248,7 +250,8 @@ class StableDiffusion:
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM Inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)     # a_tw = alpha(t-skip), a_rn = alpha(t)
             noise_uc, noise_c = self.predict_noise(zt, t, uc, c)
-            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, cfgpp, False)
+            dev_a = "tw" if int(t) - self.tables.skip < 0 else None
+            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, cfgpp, False, dev_a)
         return zt
 
     @torch.no_grad()
@@ -297,7 +300,7 @@ class StableDiffusion:
         for i in _progress(range(n), "SD"):
             sigma = sigmas[i]
             new_t = self.timestep(sigma)
-            self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma), 0)
+            self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma, self.scalar_semantics), 0)
             noise_uc, noise_c = self.predict_noise(xc, new_t, uc, c)
             first = (solver == "euler") or (not have_old)
             coef, euler = K.kdiff_coeffs(cfg_guidance, sigmas, i, first, xl_form=False, semantics=self.scalar_semantics)
@@ -330,7 +333,7 @@ class StableDiffusion:
             sigma = sigmas[i]
             new_t = self.timestep(sigma)
             sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1])
-            self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma), 0)
+            self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma, self.scalar_semantics), 0)
             noise_uc, noise_c = self.predict_noise(xc, new_t, uc, c)
             if (not two_stage) or float(sigma_down) == 0.0:
                 # Euler step down to sigma_down: x = den + ((x - d_from)/sigma) * sigma_down
@@ -347,7 +350,7 @@ class StableDiffusion:
                                     first((-h * r).expm1()), 0)
                 sigma_s = sigma_fn(s_mid)
                 t_2 = self.timestep(sigma_s)
-                self.engine.kdiff_input(x2, xc, K.kdiff_input_scale_sd(sigma_s), 0)
+                self.engine.kdiff_input(x2, xc, K.kdiff_input_scale_sd(sigma_s, self.scalar_semantics), 0)
                 nuc2, nc2 = self.predict_noise(xc, t_2, uc, c)
                 self.engine.kdiff_denoise(x2, nuc2, nc2, lam, float(sigma_s), den2, uden2)
                 ratio_n = first(sigma_fn(t_next) / sigma_fn(t))

@@ -206,7 +206,8 @@ class SDXL(StableDiffusion):
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)
             noise_uc, noise_c = self.predict_noise(zt, t, uc, c, add_cond_kwargs)
-            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, cfgpp, False)
+            dev_a = "tw" if int(t) - self.tables.skip < 0 else None      # self.alpha(t - skip) = the DEVICE-resident final alpha
+            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, cfgpp, False, dev_a)
         return zt
 
     def inversion(self, z0, uc, c, cfg_guidance, add_cond_kwargs):
@@ -230,7 +231,8 @@ class SDXL(StableDiffusion):
         for step, t in enumerate(_progress(ts, desc)):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, wrap=wrap)
             noise_uc, noise_c = self.predict_noise(zt, t, null_e, emb, add_cond_kwargs)
-            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, False, cfgpp)
+            dev_a = "rn" if (not wrap and int(t) - self.tables.skip < 0) else None
+            self._ddim_update(zt, z0t, noise_uc, noise_c, cfg_guidance, sqrt4, False, cfgpp, dev_a)
             if callback_fn is not None:
                 self._run_callback(callback_fn, step, t, z0t, zt)
         return z0t          # for the last step, do not add noise
@@ -250,7 +252,7 @@ class SDXL(StableDiffusion):
             sigma = sigmas[i]
             new_t = t_of_sigma(sigma)
             if input_mode == 0:
-                self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma), 0)
+                self.engine.kdiff_input(x, xc, K.kdiff_input_scale_sd(sigma, self.scalar_semantics), 0)
             else:
                 self.engine.kdiff_input(x, xc, float(self._alphas_2m[i].clone().sqrt()), 1)
             noise_uc, noise_c = self.predict_noise(xc, new_t, null_e, emb, add_cond_kwargs)

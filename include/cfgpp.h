@@ -36,7 +36,11 @@ const char* cfgpp_last_error(void);
  * :280-286 (CFG: 0,0), :177-180 (inversion CFG: 0,0 with coefficients swapped),
  * :905-908 (inversion CFG++: 1,0) and latent_sdxl.py:738-744, 450-456, 315-318, 970-973.
  * eps_is_half=1: eps are fp16 (the autocast UNet output) and every eps product is
- * rounded to fp16 exactly as torch promotion does.  n must be a multiple of 4. */
+ * rounded to fp16 exactly as torch promotion does.  n must be a multiple of 4.
+ * Divisors (c2 here; s of cfgpp_kdiff_input mode 0; sigma_item and two_r of cfgpp_step_kdiff) are positive on this
+ * path, and their SIGN selects how the quotient is formed: c > 0 is an IEEE division (torch-CPU); c < 0 means the
+ * caller passes c = -fl32(1/divisor) and the kernel multiplies by -c - torch's GPU `div` with a CPU-scalar divisor
+ * (`/ at.sqrt()`, `/ sigma.item()`, `/ (2*r)`), which is `a * (1/b)` with the reciprocal taken once in fp32. */
 int cfgpp_step_ddim(void* z, void* z0t_out, const void* eps_uc, const void* eps_c, int eps_is_half,
                     float lam, float c1, float c2, float c3, float c4,
                     int tweedie_uc, int renoise_uc, long n, void* stream);

@@ -123,11 +123,11 @@ def ddim_step(z, eps_uc, eps_c, lam, a_tweedie, a_renoise, tweedie_uc: bool, ren
     B = eps_uc if renoise_uc else eps_hat
     if z.dtype == H:
         pa = _smul_first(c1, A, semantics)
-        z0t = _div_s(_sub(z, pa), c2)
+        z0t = _div_s(_sub(z, pa), c2, semantics)
         zn = _add(_smul_first(c3, z0t, semantics), _smul_first(c4, B, semantics))
         return z0t, zn
     zf = _f(z)
-    z0t = (zf - _scale_eps(c1, A, semantics)) / c2
+    z0t = _div_s(zf - _scale_eps(c1, A, semantics), c2, semantics)
     zn = c3 * z0t + _scale_eps(c4, B, semantics)
     return z0t, zn
 
@@ -158,10 +158,17 @@ def _mul_s(x, s):
     return x * _s(s)
 
 
-def _div_s(x, s):
+def _div_s(x, s, semantics: str = "cpu"):
+    """``x / s`` with a 0-dim CPU scalar (or python number) divisor.  torch-CPU: IEEE division.  torch on a GPU
+    (``semantics="cuda"``): the reciprocal of a CPU-scalar divisor is taken once on the host in fp32 and the kernel
+    multiplies (ATen div_true_kernel_cuda) - pinned on the GPU box by tests/test_gpu_torch_semantics.py."""
+    s = _s(s)
+    if semantics == "cuda":
+        inv = _s(1.0) / s
+        return _h(_f(x) * inv) if x.dtype == H else x * inv
     if x.dtype == H:
-        return _h(_f(x) / _s(s))
-    return x / _s(s)
+        return _h(_f(x) / s)
+    return x / s
 
 
 def _add(a, b):

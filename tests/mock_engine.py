@@ -28,6 +28,12 @@ def _c(v):
     return torch.tensor(float(v), dtype=F)
 
 
+def _div(x, c):
+    """``x / c`` as the kernels form it (step_kernels.hip: div_as_ref): c > 0 IEEE division, c < 0 multiply by -c (the
+    host-side fp32 reciprocal: torch's GPU ``div`` with a CPU-scalar divisor)"""
+    return x * (-c) if float(c) < 0 else x / c
+
+
 def emulate_step_ddim(z, z0t_out, eps_uc, eps_c, lam, coeffs, tweedie_uc, renoise_uc):
     """what cfgpp_step_ddim computes (step_kernels.hip: ddim_step_kernel)."""
     c1, c2, c3, c4 = (_c(v) for v in coeffs)
@@ -37,7 +43,7 @@ def emulate_step_ddim(z, z0t_out, eps_uc, eps_c, lam, coeffs, tweedie_uc, renois
     if z.dtype == H:        # fp16 latent: every op rounds to fp16 (ddim_step_h_kernel)
         r = lambda t: _f(_h(t))  # noqa: E731
         pa, pb = r(_f(A) * c1), r(_f(B) * c4)
-        z0 = r(r(_f(z) - pa) / c2)
+        z0 = r(_div(r(_f(z) - pa), c2))
         zn = r(r(c3 * z0) + pb)
         z0t_out.copy_(_h(z0))
         z.copy_(_h(zn))
@@ -46,14 +52,14 @@ def emulate_step_ddim(z, z0t_out, eps_uc, eps_c, lam, coeffs, tweedie_uc, renois
         pa, pb = _f(_h(_f(A) * c1)), _f(_h(_f(B) * c4))
     else:
         pa, pb = A * c1, B * c4
-    z0 = (_f(z) - pa) / c2
+    z0 = _div(_f(z) - pa, c2)
     zn = c3 * z0 + pb
     z0t_out.copy_(z0)
     z.copy_(zn)
 
 
 def emulate_kdiff_input(x, xc, s, mode):
-    v = _f(x) / _c(s) if mode == 0 else _f(x) * _c(s)
+    v = _div(_f(x), _c(s)) if mode == 0 else _f(x) * _c(s)
     xc.copy_(_h(v))
 
 
@@ -72,13 +78,13 @@ def emulate_step_kdiff(x, den_out, old, eps_uc, eps_c, coef, variant, xl_form, e
         uden = r(xv - r(uc * sigma))
     d_from = den if variant == 0 else uden
     if euler_branch:
-        d = r(r(xv - d_from) / sigma_item)
+        d = r(_div(r(xv - d_from), sigma_item))
         xn = r(den + r(d * sigma_next))
     else:
         ov = _f(old)
         diff_a = uden if variant == 2 else den
         term1 = r(d_from * neg_exp)
-        t2 = r(r(r(diff_a - ov) * expm1) / two_r)
+        t2 = r(_div(r(r(diff_a - ov) * expm1), two_r))
         extra1 = r(term1 - t2)
         extra2 = r(xv * exp_mh)
         xn = r(r(den + extra1) + extra2)

@@ -76,8 +76,9 @@ def test_ddim_steps_fp16_latent_bit_exact(golden_h16, tag, lam, cfgpp):
 
 
 def test_cuda_scalar_semantics_differs_only_by_scalar_rounding():
-    """"cuda" semantics (the product default) = the same formulas with the scalar-first coefficients left in
-    fp32; it is unpinned (no CUDA torch here), so at least check it is what it claims to be."""
+    """"cuda" semantics (the product default) = the same formulas with the scalar-first coefficients left in fp32 and
+    the scalar divisor applied as a host-side fp32 reciprocal.  Here (no GPU) only that the oracle says what it claims;
+    the pin against torch-ROCm evaluating the reference's expressions is tests/test_gpu_torch_semantics.py."""
     g = torch.Generator().manual_seed(0)
     z = torch.randn(1, 4, 8, 8, generator=g)
     eu, ec = (torch.randn(1, 4, 8, 8, generator=g).half() for _ in range(2))
@@ -87,7 +88,7 @@ def test_cuda_scalar_semantics_differs_only_by_scalar_rounding():
     a1, b1 = O.ddim_step(z, eu, ec, 0.6, None, None, False, True, sqrt4=s4, semantics="cuda")
     hat = O.cfg_mix(eu, ec, 0.6)
     c1, c2, c3, c4 = (torch.tensor(float(v)) for v in s4)
-    want_a = (z - (hat.float() * c1).half().float()) / c2
+    want_a = (z - (hat.float() * c1).half().float()) * (torch.tensor(1.0) / c2)
     want_b = c3 * want_a + (eu.float() * c4).half().float()
     assert torch.equal(a1, want_a) and torch.equal(b1, want_b)
     assert not torch.equal(a0, a1) and float((a0 - a1).abs().max()) < 2e-3 * float(a1.abs().max())
