@@ -103,6 +103,8 @@ PROTOTYPES = {
     "cfgpp_igemm_set_mf16_heads": (None, [_I]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
+    "cfgpp_igemm_timeline": (None, [_P, _L, _I]),
+    "cfgpp_igemm_timeline_info": (None, [C.POINTER(C.c_int)]),
     "cfgpp_groupnorm_set_mode": (None, [_I]),
     "cfgpp_layernorm_set_rows_per_wave": (None, [_I]),
     "cfgpp_attention_set_dma": (None, [_I]),

@@ -5,7 +5,11 @@ The reference builds everything with ``StableDiffusionPipeline.from_pretrained(m
 copy of such a checkpoint (no hub access here) the same components map onto this package as
 
     <dir>/unet/diffusion_pytorch_model.safetensors          -> unet_weights=   (HIP UNet engine)
-    <dir>/vae/diffusion_pytorch_model.safetensors           -> vae_weights=    (HIP VAE engine)
+    <dir>/vae/diffusion_pytorch_model.safetensors           -> vae_weights=    (HIP VAE engine; SD1.5 only)
+    <dir>/vae_fp16_fix/diffusion_pytorch_model.safetensors  -> vae_weights=    (SDXL: the reference REPLACES the pipeline's VAE with
+                                                               madebyollin/sdxl-vae-fp16-fix, latent_sdxl.py:44,396 - the stock
+                                                               SDXL VAE overflows in fp16, which is what the HIP VAE computes in;
+                                                               <dir>/vae is never used for SDXL unless vae_dir= says so)
     <dir>/text_encoder/{config.json, model.safetensors} + <dir>/tokenizer/{vocab.json, merges.txt}        -> text_encoder=
     <dir>/text_encoder_2/... + <dir>/tokenizer_2/...        (SDXL: second tower, projected pooled output, "!" padding)
 
@@ -26,13 +30,24 @@ def _first(*paths):
     return None
 
 
-def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda") -> Tuple[Dict, List[str]]:
-    """(kwargs for ``get_solver``, names of the components not found)."""
+def _weights_in(folder, stem="diffusion_pytorch_model"):
+    return _first(os.path.join(folder, stem + ".safetensors"), os.path.join(folder, stem + ".fp16.safetensors"))
+
+
+def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None) -> Tuple[Dict, List[str]]:
+    """(kwargs for ``get_solver``, names of the components not found).  ``vae_dir``: a folder holding the VAE weights,
+    overriding the default lookup (SD1.5: ``<dir>/vae``; SDXL: ``<dir>/vae_fp16_fix`` or ``<dir>/sdxl-vae-fp16-fix`` -
+    NEVER ``<dir>/vae``, whose fp16 activations overflow)."""
     from .conditioning import ClipTextTower
     d = str(model_dir)
     kw, missing = {}, []
-    unet = _first(os.path.join(d, "unet", "diffusion_pytorch_model.safetensors"), os.path.join(d, "unet", "diffusion_pytorch_model.fp16.safetensors"))
-    vae = _first(os.path.join(d, "vae", "diffusion_pytorch_model.safetensors"), os.path.join(d, "vae", "diffusion_pytorch_model.fp16.safetensors"))
+    unet = _weights_in(os.path.join(d, "unet"))
+    if vae_dir is not None:
+        vae = _weights_in(str(vae_dir))
+    elif sdxl:
+        vae = _weights_in(os.path.join(d, "vae_fp16_fix")) or _weights_in(os.path.join(d, "sdxl-vae-fp16-fix"))
+    else:
+        vae = _weights_in(os.path.join(d, "vae"))
     if unet:
         kw["unet_weights"] = unet
     else:
@@ -40,13 +55,13 @@ def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda") -> Tuple[Dict, 
     if vae:
         kw["vae_weights"] = vae
     else:
-        missing.append("vae")
+        missing.append("vae (SDXL needs madebyollin/sdxl-vae-fp16-fix in <dir>/vae_fp16_fix)" if sdxl else "vae")
     on_gpu = torch.device(device).type == "cuda"
     dtype = torch.float16 if on_gpu else torch.float32          # the reference runs the text encoders in the pipeline's fp16
 
     def tower(enc, tok, **args):
         e, t = os.path.join(d, enc), os.path.join(d, tok)
-        ok = all(os.path.exists(os.path.join(e, f)) for f in ("config.json", "model.safetensors")) and \
+        ok = os.path.exists(os.path.join(e, "config.json")) and _weights_in(e, "model") is not None and \
             all(os.path.exists(os.path.join(t, f)) for f in ("vocab.json", "merges.txt"))
         if not ok:
             missing.append(enc)

@@ -209,7 +209,9 @@ class ClipTextTower:
         self = cls.__new__(cls)
         cfg = CLIPTextConfig.from_json_file(os.path.join(str(encoder_dir), "config.json"))
         self.model = (CLIPTextModelWithProjection(cfg) if with_projection else CLIPTextModel(cfg)).eval()
-        sd = dict(load_safetensors_iter(os.path.join(str(encoder_dir), "model.safetensors")))
+        wfile = next((f for f in (os.path.join(str(encoder_dir), n) for n in ("model.safetensors", "model.fp16.safetensors")) if os.path.exists(f)),
+                     os.path.join(str(encoder_dir), "model.safetensors"))       # the fp16 variant is the common SDXL download
+        sd = dict(load_safetensors_iter(wfile))
         sd.pop("text_model.embeddings.position_ids", None)         # a buffer older checkpoints still carry
         self.model.load_state_dict(sd)
         self.model.to(device=device, dtype=dtype)

@@ -29,6 +29,30 @@
 
 namespace {
 
+// diagnostics: wave 0 / lane 0 of a workgroup stamps slot `slot` of its timeline record (IGemmArgs::tl, normally null)
+__device__ __forceinline__ void tl_stamp(unsigned long long* tl, int slot) {
+    if (tl != nullptr && threadIdx.x == 0) tl[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void tl_begin(unsigned long long* tl) {
+    if (tl != nullptr && threadIdx.x == 0) {
+        unsigned long long* r = tl + (long)blockIdx.x * 8;
+        r[0] = __builtin_amdgcn_s_memtime();
+        r[4] = __builtin_amdgcn_s_memrealtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        r[6] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+}
+__device__ __forceinline__ void tl_end(unsigned long long* tl) {
+    if (tl != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores have left
+        if (threadIdx.x == 0) {
+            unsigned long long* r = tl + (long)blockIdx.x * 8;
+            r[3] = __builtin_amdgcn_s_memtime();
+            r[5] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+
 __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
     const int b = m / HW, p = m - b * HW;
     const int y = p / W, x = p - y * W;
@@ -357,6 +381,7 @@ igemm_kernel(const IGemmArgs p) {
     constexpr int STAGE_BYTES = (BM + BN) * 128;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    tl_begin(p.tl);
 
     // ---- workgroup -> (tile, k-range).  Blocks [0, n_main) own one whole tile each (XCD-aware order:
     // block b runs on XCD b % 8, consecutive tiles share activation rows).  Blocks >= n_main are the
@@ -542,6 +567,7 @@ igemm_kernel(const IGemmArgs p) {
         if (NST > 2 && nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");   // NST-1 tiles issued: the oldest has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        tl_stamp(p.tl, 1);
         // one K-tile: MFMAs on stage `cur`; DMA (if any) of tile `ktn` into stage `nxt`; wait + barrier
         auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma) {
             constexpr bool DMA = decltype(with_dma)::value;
@@ -664,9 +690,12 @@ igemm_kernel(const IGemmArgs p) {
             }
         };
         int kt = kt_begin;
-        for (; kt + NST - 1 < kt_end; ++kt)
+        for (; kt + NST - 1 < kt_end; ++kt) {
             tile_body(kt, (kt - kt_begin) % NST, kt + NST - 1, (kt - kt_begin + NST - 1) % NST, std::true_type{});
+            if (kt == kt_begin) tl_stamp(p.tl, 7);
+        }
         for (; kt < kt_end; ++kt) tile_body(kt, (kt - kt_begin) % NST, 0, 0, std::false_type{});
+        tl_stamp(p.tl, 2);
     } else {
         load_tile(kt_begin);
         store_tile(0);
@@ -738,17 +767,20 @@ igemm_kernel(const IGemmArgs p) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ws[(long)((i * NT + j) * 16 + r) * NTHR] = acc[i][j][r];
+        tl_end(p.tl);
         return;
     }
     constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
     if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
         igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)));
+        tl_end(p.tl);
         return;
     }
     if constexpr (NT % 2 == 0) {
         if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
             igemm_epilogue_geglu_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)));
+            tl_end(p.tl);
             return;
         }
     }
@@ -757,9 +789,11 @@ igemm_kernel(const IGemmArgs p) {
     if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
         (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
         igemm_epilogue_heads_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560));
+        tl_end(p.tl);
         return;
     }
     igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
+    tl_end(p.tl);
 }
 
 // Finishes the K-split tiles: block (t, ij) sums the ksplit fp32 partials of ONE 32x32 MFMA sub-tile
@@ -950,6 +984,7 @@ igemm16_kernel(const IGemmArgs p) {
     constexpr int NM = 20;                          // MFMAs per wave per K-tile: 2 k-steps x (2 x 5) tiles
     static_assert(NST >= 3 && NST <= 4, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    tl_begin(p.tl);
 
     const int bid = blockIdx.x;
     int wg;
@@ -1066,6 +1101,7 @@ igemm16_kernel(const IGemmArgs p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    tl_stamp(p.tl, 1);
 
     auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma) {
         constexpr bool DMA = decltype(with_dma)::value;
@@ -1119,16 +1155,30 @@ igemm16_kernel(const IGemmArgs p) {
         asm volatile("" ::: "memory");
     };
     int kt = 0;
-    for (; kt + NST - 1 < nk; ++kt) tile_body(kt, kt % NST, kt + NST - 1, (kt + NST - 1) % NST, std::true_type{});
+    for (; kt + NST - 1 < nk; ++kt) {
+        tile_body(kt, kt % NST, kt + NST - 1, (kt + NST - 1) % NST, std::true_type{});
+        if (kt == 0) tl_stamp(p.tl, 7);
+    }
     for (; kt < nk; ++kt) tile_body(kt, kt % NST, 0, 0, std::false_type{});
+    tl_stamp(p.tl, 2);
 #undef CFGPP_WAIT_TILES
 
     // the k-loop ended with vmcnt(0) + barrier: LDS is free for the per-wave transposes
     if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536));
     else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
+    tl_end(p.tl);
 }
 
 // ---- launch + tail scheduling ------------------------------------------------------------------
+// diagnostics: per-workgroup timeline of the `target`-th igemm_launch call after the (re)arming call
+static unsigned long long* g_tl = nullptr; static long g_tl_cap = 0; static int g_tl_target = -1, g_tl_count = 0;
+static int g_tl_info[12] = {0};                     // {cfg, grid, threads, BM, BN, NST, ksplit, n_major, M, N, K, epi} of the recorded launch
+static unsigned long long* tl_take(int cfg, int grid, int threads, int BM, int BN, int NST, const IGemmArgs& a) {
+    if (!a.tl || grid > g_tl_cap) return nullptr;
+    const int info[12] = {cfg, grid, threads, BM, BN, NST, a.ksplit, a.n_major, a.M, a.N, a.K, a.epi};
+    for (int i = 0; i < 12; ++i) g_tl_info[i] = info[i];
+    return g_tl;
+}
 static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
 constexpr long WS_BYTES = 128L << 20;               // fp32 partials of one launch: T * S * BM * BN * 4 bytes must fit
 static int g_staged_epi = 1;
@@ -1183,6 +1233,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     const int n_tail = T - a.n_main;
     if (n_tail > 0) a.n_major = 0;                     // K-split tiles keep the M-major numbering the reduce kernel uses
     a.walk_div = a.n_major ? cdiv(a.M, BM) : cdiv(a.N, BN);
+    a.tl = tl_take(WM * 100 + WN * 10 + (GLDS ? 1 : 0), a.n_main + n_tail * a.ksplit, NTHR, BM, BN, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main + n_tail * a.ksplit), dim3(NTHR), smem, stream, a);
     if (n_tail > 0)
         hipLaunchKernelGGL((igemm_reduce_kernel<WM, WN, WTM, WTN>), dim3(n_tail, (WTM / 32) * (WTN / 32)), dim3(NTHR), 0, stream, a);
@@ -1230,6 +1281,7 @@ int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    a.tl = tl_take(16, a.n_main, 512, 128, 160, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(512), smem, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1316,9 +1368,18 @@ static unsigned g_tune_mask = 0xffffffffu;   // bit c: the tuner may pin tile co
 extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
 unsigned igemm_tune_mask() { return g_tune_mask; }
 
+// Arms the timeline: the `target`-th igemm_launch call from now on (0-based) records {entry, first tile landed, k-loop done,
+// stores done} per workgroup into buf[grid][8] (device memory, >= cap_blocks * 64 bytes); buf = null disarms.
+extern "C" void cfgpp_igemm_timeline(void* buf, long cap_blocks, int target) {
+    g_tl = (unsigned long long*)buf; g_tl_cap = buf ? cap_blocks : 0; g_tl_target = buf ? target : -1; g_tl_count = 0;
+}
+extern "C" void cfgpp_igemm_timeline_info(int* out12) { for (int i = 0; i < 12; ++i) out12[i] = g_tl_info[i]; }
+
 int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.allow_split = 1;
+    a.tl = nullptr;
+    if (g_tl) { if (g_tl_count == g_tl_target) a.tl = g_tl; ++g_tl_count; }
     const int Cin = a.C0 + a.C1;
     CFGPP_REQUIRE(a.C0 > 0 && a.C0 % 64 == 0 && a.C1 % 64 == 0, "igemm: C0=%d C1=%d must be multiples of 64", a.C0, a.C1);
     CFGPP_REQUIRE(a.taps == 1 || a.taps == 9, "igemm: taps=%d", a.taps);

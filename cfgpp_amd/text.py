@@ -63,7 +63,9 @@ class HipClipTextTower:
                                pad_token=pad_token)
         return cls(cfg["vocab_size"], cfg["hidden_size"], cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["intermediate_size"],
                    cfg.get("hidden_act", "quick_gelu"), cfg.get("projection_dim") if with_projection else None,
-                   os.path.join(str(encoder_dir), "model.safetensors"), tok, penultimate, max_batch=max_batch, device=device)
+                   next((f for f in (os.path.join(str(encoder_dir), n) for n in ("model.safetensors", "model.fp16.safetensors"))
+                         if os.path.exists(f)), os.path.join(str(encoder_dir), "model.safetensors")),
+                   tok, penultimate, max_batch=max_batch, device=device)
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -143,3 +143,19 @@ def test_model_dir_flag_plugs_real_text_path(tmp_path, capsys):
     assert t1.penultimate and t2.penultimate and t2.proj and not t1.proj and t2.tok.pad_id == t2.tok.vocab["!"]
     h1, _ = t1(["a cat"]); h2, p2 = t2(["a cat"])
     assert torch.cat([h1, h2], -1).shape == (1, 77, 128) and p2.shape == (1, 32)
+    # SDXL never takes the pipeline's own <dir>/vae (latent_sdxl.py:44 swaps in sdxl-vae-fp16-fix: the stock VAE overflows in fp16)
+    from safetensors.torch import save_file
+    (xl / "vae").mkdir(); (xl / "unet").mkdir()
+    save_file({"w": torch.zeros(1)}, str(xl / "vae" / "diffusion_pytorch_model.safetensors"))
+    save_file({"w": torch.zeros(1)}, str(xl / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    found, missing = solver_kwargs_from_dir(xl, sdxl=True, device="cpu")
+    assert "vae_weights" not in found and any(m.startswith("vae") for m in missing) and found["unet_weights"].endswith(".fp16.safetensors")
+    (xl / "vae_fp16_fix").mkdir()
+    save_file({"w": torch.zeros(1)}, str(xl / "vae_fp16_fix" / "diffusion_pytorch_model.safetensors"))
+    found, missing = solver_kwargs_from_dir(xl, sdxl=True, device="cpu")
+    assert found["vae_weights"].endswith(os.path.join("vae_fp16_fix", "diffusion_pytorch_model.safetensors")) and not any(m.startswith("vae") for m in missing)
+    assert solver_kwargs_from_dir(xl, sdxl=True, device="cpu", vae_dir=xl / "vae")[0]["vae_weights"].endswith(os.path.join("vae", "diffusion_pytorch_model.safetensors"))
+    # fp16-variant text-encoder weights (model.fp16.safetensors, the common SDXL download) are found too
+    os.rename(xl / "text_encoder" / "model.safetensors", xl / "text_encoder" / "model.fp16.safetensors")
+    found, missing = solver_kwargs_from_dir(xl, sdxl=True, device="cpu")
+    assert "text_encoder" in found and "text_encoder" not in missing

@@ -9,7 +9,7 @@
   level) and of the real SDXL net at 4 rows @ 128x128, and a 4-step real-SD1.5 batch-8 chain, vs the oracle;
 * the fp16-latent step kernel (inversion / edit dtype flow of the reference) bit-exact vs the golden vectors.
 
-Tolerances are 2x what was measured on the MI355X (recorded in gpurun_out/parity_r02.jsonl by these tests).
+Tolerances are 2x what was measured on the MI355X (recorded in gpurun_out/parity_r03.jsonl by these tests).
 Both sides of a chain test use the same scalar semantics ("cuda" = the product default, see cfgpp_amd/coeffs.py).
 """
 import json
@@ -31,10 +31,10 @@ def T(a):
 
 
 def record(test, **kw):
-    """append measured errors to gpurun_out/parity_r02.jsonl (tolerances are set from these)"""
+    """append measured errors to gpurun_out/parity_r03.jsonl (tolerances are set from these)"""
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_r03.jsonl"), "a") as f:
             f.write(json.dumps(dict(test=test, **kw)) + "\n")
     except OSError:
         pass
@@ -266,10 +266,10 @@ def test_ancestral_solver_chain_vs_oracle_pinned_noise(name, lam, tol):
 
 
 # ------------------------------------------------------------------ the benchmark's own sizes
-@pytest.mark.parametrize("cfg_name,R,hw,tol", [("sd15", 16, 64, 2.5e-3), ("sdxl", 4, 128, 2.5e-3)])
+@pytest.mark.parametrize("cfg_name,R,hw,tol", [("sd15", 16, 64, 2.5e-3)])
 def test_real_unet_forward_at_bench_size(cfg_name, R, hw, tol):
     """C2's forward (SD1.5, 16 rows @ 64x64: autotuned 256-wide tiles, K-split 8x8 level, d = 40 attention at N = 4096)
-    and C3's (SDXL, 4 rows @ 128x128: M = 16384 convs, N = 4096 d = 64 attention) vs the fp32 oracle; autotune ON."""
+    vs the fp32 oracle; autotune ON."""
     need_gpu()
     import gpu_diag
     t0 = time.time()
@@ -278,6 +278,47 @@ def test_real_unet_forward_at_bench_size(cfg_name, R, hw, tol):
     record("real_unet_forward", cfg=cfg_name, rows=R, hw=hw, rel_l2=st["rel_l2"], max_abs=st["max_abs"], cpu_ref_s=st["cpu_ref_s"],
            total_s=round(time.time() - t0, 1))
     assert st["finite"] and st["rel_l2"] < tol, f"{cfg_name} rows={R} @{hw}: {st}"
+
+
+def test_real_sdxl_forward_at_every_bench_plan_size():
+    """The real SDXL net @ 128x128 latents at the row counts of all three SDXL workloads - 4 rows (C3: batch 2 per GPU),
+    2 rows (C5: batch-1 edit job; M = 2048 at the 32x32 level -> the K-split rule) and 16 rows (C4: Lightning batch 8;
+    16-row pools, multi-round grids) - vs the fp32 oracle, autotune ON.  The oracle runs ONCE on 4 distinct rows
+    (2 latents x {uc, c} contexts); the 2- and 16-row inputs are built from those rows (the net has no cross-row
+    term), so every output row of every plan has its own oracle row."""
+    need_gpu()
+    import hip_ops as H
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import CONFIGS
+    from cfgpp_amd.weights import synth_state_dict
+    from gpu_diag import rnd
+    from oracle.unet_ref import UNetRef
+    cfg, hw, tval = CONFIGS["sdxl"], 128, 501.0
+    sd = synth_state_dict(cfg, 0)
+    z = rnd(2, 4, hw, hw, seed=50)
+    ehs = rnd(4, 77, cfg.cross_attention_dim, scale=0.5, seed=51)
+    te = rnd(4, cfg.addition_pooled_dim, scale=0.5, seed=52)
+    ti = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * 4)
+    net = HipUNet(cfg, max_rows=16, sample_hw=(hw, hw))
+    net.load_state_dict(sd).finalize()
+    # oracle row j: latent j % 2, context j
+    plans = {4: ([0, 1], [0, 1, 2, 3]),
+             2: ([0], [0, 2]),
+             16: ([0, 1] * 4, [(r % 2) + 2 * ((r // 2) % 2) for r in range(16)])}
+    outs = {}
+    for R, (zi, ci) in plans.items():
+        net.set_context(ehs[ci], te[ci], ti[ci])
+        outs[R] = (net.forward(z[zi].to(H.DEV), tval).float().cpu(), ci)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ref = UNetRef(cfg, sd)(torch.cat([z, z]), tval, ehs, {"text_embeds": te, "time_ids": ti})["sample"]
+    cpu_s = round(time.time() - t0, 1)
+    for R, (got, ci) in outs.items():
+        st = H.err_stats(got, ref[ci])
+        record("real_unet_forward", cfg="sdxl", rows=R, hw=hw, rel_l2=st["rel_l2"], max_abs=st["max_abs"], cpu_ref_s=cpu_s)
+        assert st["finite"] and st["rel_l2"] < 2.5e-3, f"sdxl rows={R} @{hw}: {st}"          # measured 1.1e-3 at 4 rows
+        worst = max(float((got[r] - ref[ci[r]]).norm() / ref[ci[r]].norm()) for r in range(R))
+        assert worst < 4e-3, f"sdxl rows={R}: worst single row rel-L2 {worst:.3e}"
 
 
 def test_real_sd15_batch8_chain_4_steps():
@@ -366,6 +407,33 @@ def test_vae_decode_at_512():
     rel = rel_l2(img, ref)
     record("vae_decode_512", rel_l2=rel, cpu_ref_s=round(time.time() - t0, 1))
     assert img.shape == (1, 3, 512, 512) and torch.isfinite(img).all() and rel < 3e-3, rel          # measured 1.2e-3
+
+
+def test_vae_decode_and_encode_at_1024():
+    """SDXL's VAE passes (latent_sdxl.py:150-164): 128x128 latent <-> 1024x1024 image - the mid-block attention runs
+    over 16384 tokens with one 512-wide head - decode AND encode (pinned posterior noise) vs the fp32 restatement."""
+    need_gpu()
+    from cfgpp_amd.vae import HipVAE, synth_vae_state_dict
+    from oracle.vae_ref import VAERef
+    sd = synth_vae_state_dict(0)
+    scale = 0.13025
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn((1, 4, 128, 128), generator=g) * scale * 1.5
+    x = torch.rand((1, 3, 1024, 1024), generator=g) * 2 - 1
+    noise = torch.randn((1, 4, 128, 128), generator=g)
+    hip = HipVAE(scale, (128, 128), max_batch=1, state_dict=sd)
+    img = hip.decode(z.cuda()).cpu()
+    zz, mom = hip.encode(x, noise=noise, return_moments=True)
+    zz, mom = zz.cpu(), mom.cpu()
+    t0 = time.time()
+    ref = VAERef(scale, device="cpu", dtype=torch.float32, state_dict=sd)
+    ref_img = ref.decode(z)
+    mean, logvar = ref.encode_moments(x)
+    ref_z = (mean + torch.exp(0.5 * logvar) * noise) * scale
+    rel_d, rel_m, rel_z = rel_l2(img, ref_img), rel_l2(mom, torch.cat([mean, logvar], dim=1)), rel_l2(zz, ref_z)
+    record("vae_1024", rel_decode=rel_d, rel_moments=rel_m, rel_latent=rel_z, cpu_ref_s=round(time.time() - t0, 1))
+    assert img.shape == (1, 3, 1024, 1024) and torch.isfinite(img).all() and torch.isfinite(zz).all()
+    assert rel_d < 3e-3 and rel_m < 1e-2 and rel_z < 1e-2, (rel_d, rel_m, rel_z)      # 512^2: decode 1.2e-3, encode moments 8e-4
 
 
 def test_groupnorm_large_mean_small_variance():
