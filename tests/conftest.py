@@ -34,3 +34,15 @@ def golden_h16():
     with open(os.path.join(ROOT, "tests", "golden", "sampler_golden_h16.json")) as f:
         meta = json.load(f)
     return g, meta
+
+
+@pytest.fixture(scope="session")
+def golden_r3():
+    """round-3 additions recorded from the reference: SDXL euler / *_lightning trajectories, the 'npi' initialisation"""
+    import json
+
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sampler_golden_r3.npz"))
+    with open(os.path.join(ROOT, "tests", "golden", "sampler_golden_r3.json")) as f:
+        meta = json.load(f)
+    return g, meta

@@ -319,3 +319,50 @@ np.savez_compressed(os.path.join(HERE, "sampler_golden_h16.npz"), **out)
 with open(os.path.join(HERE, "sampler_golden_h16.json"), "w") as f:
     json.dump(meta, f, indent=1, sort_keys=True)
 print("wrote", len(out), "fp16-latent arrays;", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+# ----------------------------------------------------------------------------
+# G8 (round 3): the registry names that had no trajectory of their own - SDXL `euler`, `ddim_lightning`,
+# `euler_lightning`, `euler_cfg++_lightning` (latent_sdxl.py:469, 519, 541, 810) - and the 'npi' initialisation
+# (null-prompt inversion with the prompt embedding on both rows at cfg_guidance = 1; latent_diffusion.py:193-197,
+# latent_sdxl.py:280-286).  A third file, so the first two keep regenerating bit-identically.
+# ----------------------------------------------------------------------------
+out.clear()
+meta.clear()
+run_xl("euler", "G8/xl_euler_cfg", 10, 5.0)
+run_xl("ddim_lightning", "G8/xl_light_ddim_cfg", 4, 1.0)
+run_xl("euler_lightning", "G8/xl_light_euler_cfg", 4, 1.0)
+run_xl("euler_cfg++_lightning", "G8/xl_light_euler_cfgpp", 4, 1.0)
+
+
+def run_npi(kind, tag, latent_dtype):
+    stub.FakeVAE.latent_dtype = latent_dtype
+    torch.manual_seed(42)
+    g = torch.Generator().manual_seed(7)
+    if kind == "sd":
+        s = ref_sd.get_solver("ddim_cfg++", solver_config=cfg(10), device="cpu", pipe_dtype=torch.float16)
+        log = hook_unet(s.unet)
+        src_img = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+        uc, c = s.get_text_embed(null_prompt=NULL, prompt=PROMPT)
+        z = s.initialize_latent(method="npi", src_img=src_img, uc=uc, c=c)
+    else:
+        s = ref_xl.get_solver("ddim_cfg++", solver_config=cfg(10), device="cpu")
+        log = hook_unet(s.unet)
+        src_img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+        null_e, e, pool_null, pool = s.get_text_embed(NULL, PROMPT, NULL, PROMPT)
+        ack = {"text_embeds": torch.cat([pool_null, pool], dim=0), "time_ids": torch.ones(2, 6)}
+        z = s.initialize_latent(method="npi", src_img=src_img, add_cond_kwargs=ack, uc=null_e, c=e)
+        meta[tag + "/ack_rows_after"] = [int(ack["text_embeds"].shape[0]), int(ack["time_ids"].shape[0])]
+    dump_unet_log(tag, log)
+    out[tag + "/z"] = npy(crop(z))
+    meta[tag] = dict(kind=kind, nfe=10, z_dtype=str(z.dtype))
+    stub.FakeVAE.latent_dtype = None
+
+
+run_npi("sd", "G8/sd_npi", None)
+run_npi("sd", "G8/sd_npi_h", torch.float16)
+run_npi("xl", "G8/xl_npi", None)
+run_npi("xl", "G8/xl_npi_h", torch.float16)
+np.savez_compressed(os.path.join(HERE, "sampler_golden_r3.npz"), **out)
+with open(os.path.join(HERE, "sampler_golden_r3.json"), "w") as f:
+    json.dump(meta, f, indent=1, sort_keys=True)
+print("wrote", len(out), "round-3 arrays;", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")

@@ -275,6 +275,62 @@ def test_sdxl_edit_trajectory(golden, name, tag, lam):
     assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"]))
 
 
+@pytest.mark.parametrize("name,tag,nfe,lam", [("euler", "G8/xl_euler_cfg", 10, 5.0), ("ddim_lightning", "G8/xl_light_ddim_cfg", 4, 1.0),
+                                              ("euler_lightning", "G8/xl_light_euler_cfg", 4, 1.0),
+                                              ("euler_cfg++_lightning", "G8/xl_light_euler_cfgpp", 4, 1.0)])
+def test_sdxl_trajectory_remaining_names(golden_r3, name, tag, nfe, lam):
+    """the four latent_sdxl registry names that shared a loop with a tested name but had no golden trajectory of their
+    own (latent_sdxl.py:469, 519, 541, 810): every UNet input and every (z0t, zt) of the reference's run"""
+    g, meta = golden_r3
+    s, eng = make_xl(name, nfe)
+    rec = Rec()
+    p = meta[tag]["prompts"]
+    s.sample(prompt1=p, prompt2=p, cfg_guidance=lam, target_size=(64, 64), original_size=(64, 64), callback_fn=rec, seeds=[42],
+             return_latents=True)
+    uz, ut = T(g[tag + "/unet_z"]), T(g[tag + "/unet_t"])
+    assert len(eng.calls) == uz.shape[0] == nfe
+    for i, c in enumerate(eng.calls):
+        assert c["z"].dtype == uz.dtype and torch.equal(c["z"], uz[i][0:1]), f"unet call {i}"
+        assert float(c["t"]) == float(ut[i][0]), (i, float(c["t"]), float(ut[i][0]))
+    assert torch.equal(torch.stack(rec.z0t), T(g[tag + "/z0t"])) and torch.equal(torch.stack(rec.zt), T(g[tag + "/zt"]))
+    assert [float(t) for t in rec.ts] == [float(t) for t in g[tag + "/cb_t"]]
+    assert s._ctx_keep[2].shape[0] == int(g[tag + "/unet_te_rows"][0])          # Q7: lambda == 1 -> positive rows only
+    if "lightning" in name:
+        with pytest.raises(AssertionError):                                      # "CFG should be turned off in the lightning version"
+            s.sample(prompt1=p, prompt2=p, cfg_guidance=0.6, target_size=(64, 64), original_size=(64, 64), seeds=[42], return_latents=True)
+
+
+@pytest.mark.parametrize("kind,tag", [("sd", "G8/sd_npi"), ("sd", "G8/sd_npi_h"), ("xl", "G8/xl_npi"), ("xl", "G8/xl_npi_h")])
+def test_npi_initialisation(golden_r3, kind, tag):
+    """``initialize_latent(method='npi')`` (latent_diffusion.py:193-197, latent_sdxl.py:280-286): inversion of the encoded
+    source with the PROMPT embedding on both rows at cfg_guidance = 1 - fp32 and fp16 (the reference's real dtype) latents"""
+    g, meta = golden_r3
+    null = "low quality,jpeg artifacts,blurry,poorly drawn,ugly,worst quality,"
+    prompt = "a photo of an astronaut riding a horse on mars"
+    uz = T(g[tag + "/unet_z"])
+    z0 = uz[0][0:1].clone()                        # the latent the reference's VAE stub produced = first UNet input
+    if kind == "sd":
+        s, eng = make_sd("ddim_cfg++", 10)
+        s.encode = lambda x: z0
+        uc, c = s.get_text_embed(null_prompt=null, prompt=prompt)
+        z = s.initialize_latent(method="npi", src_img=torch.zeros(1, 3, 64, 64), uc=uc, c=c)
+    else:
+        s, eng = make_xl("ddim_cfg++", 10)
+        s.encode = lambda x: z0
+        null_e, e, pool_null, pool = s.get_text_embed(null, prompt, null, prompt)
+        ack = {"text_embeds": torch.cat([pool_null, pool], dim=0), "time_ids": torch.ones(2, 6)}
+        z = s.initialize_latent(method="npi", src_img=torch.zeros(1, 3, 64, 64), add_cond_kwargs=ack, uc=null_e, c=e)
+        assert [int(ack["text_embeds"].shape[0]), int(ack["time_ids"].shape[0])] == meta[tag + "/ack_rows_after"]      # reduced in place
+    assert len(eng.calls) == uz.shape[0] == 10
+    for i, c_ in enumerate(eng.calls):
+        assert c_["z"].dtype == uz.dtype and torch.equal(c_["z"], uz[i][0:1]), f"unet call {i}"
+    want = T(g[tag + "/z"])
+    assert str(z.dtype) == meta[tag]["z_dtype"] and torch.equal(z.cpu(), want)
+    # both rows carried the prompt embedding: the two eps halves of every call are the same tensor
+    ue = T(g[tag + "/unet_eps"])
+    assert torch.equal(ue[:, 0], ue[:, 1])
+
+
 # ------------------------------------------------------------------ G5 conditioning
 def test_sdxl_conditioning(golden):
     g, meta = golden
