@@ -99,3 +99,28 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(xs: Sequence[float], device) -> List[List[float]]:
+    """every rank's list of floats (equal length) on every rank: [[rank 0's ...], [rank 1's ...], ...]"""
+    if not dist.is_initialized():
+        return [list(xs)]
+    t = torch.tensor(list(xs), dtype=torch.float64, device=device)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [[float(v) for v in b.cpu()] for b in bufs]
+
+
+def broadcast_ints(values: Optional[Sequence[int]], device, src: int = 0) -> List[int]:
+    """a list of ints known on ``src`` only (e.g. the tile configs rank 0's in-situ tuning pinned) -> every rank.
+    Two small collectives (length, payload); outside the sampling loop."""
+    if not dist.is_initialized():
+        return list(values or [])
+    rank = dist.get_rank()
+    n = torch.tensor([len(values) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    buf = torch.zeros(int(n.item()), dtype=torch.int64, device=device)
+    if rank == src:
+        buf.copy_(torch.tensor(list(values), dtype=torch.int64))
+    dist.broadcast(buf, src=src)
+    return [int(v) for v in buf.cpu()]

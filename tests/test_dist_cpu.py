@@ -26,8 +26,10 @@ def _worker(rank, world, port, q):
     counts = [D.shard_range(total, i, w)[1] - D.shard_range(total, i, w)[0] for i in range(w)]
     gathered = D.gather_rows(local, counts)
     mx = D.max_over_ranks(float(r + 1), torch.device("cpu"))
+    hints = D.broadcast_ints([5, 0, 14, 69] if r == 0 else None, torch.device("cpu"))      # rank 0's pinned tile configs
+    times = D.gather_floats([1.0 + r, 2.0 + r], torch.device("cpu"))
     D.barrier()
-    q.put((r, [float(x.float().sum()) for x in got], (lo, hi), None if gathered is None else gathered.reshape(-1).tolist(), mx))
+    q.put((r, [float(x.float().sum()) for x in got], (lo, hi), None if gathered is None else gathered.reshape(-1).tolist(), mx, hints, times))
 
 
 def test_world2_broadcast_shard_gather():
@@ -50,6 +52,8 @@ def test_world2_broadcast_shard_gather():
     assert res[0][3] is not None and res[1][3] is None
     assert all(abs(a - b) < 1e-3 for a, b in zip(res[0][3], want))
     assert res[0][4] == res[1][4] == 2.0
+    assert res[0][5] == res[1][5] == [5, 0, 14, 69]
+    assert res[0][6] == res[1][6] == [[1.0, 2.0], [2.0, 3.0]]
 
 
 def test_shard_range_covers_everything():
