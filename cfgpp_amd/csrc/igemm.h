@@ -55,8 +55,9 @@ struct IGemmArgs {
     int walk_hint;            // decoded from cfg_hint by igemm_launch
     int split;                // >= 2: K-split every tile this many ways (igemm_launch's big-tile rule / diagnostics); 0: launcher's rule
     // ---- diagnostics (cfgpp_igemm_timeline): per-workgroup time stamps of ONE chosen launch, null otherwise ----
-    unsigned long long* tl;   // [grid][8]: s_memtime at {entry, first tile landed, k-loop done, stores done}, s_memrealtime at
-                              // {entry, exit}, HW_ID | XCC_ID << 32, s_memtime after the first K-tile
+    unsigned long long* tl;   // [grid][16]: s_memtime at {entry, first tile landed, k-loop done, stores done}, s_memrealtime at
+                              // {entry, exit}, HW_ID | XCC_ID << 32, s_memtime after the first K-tile, s_memtime {before the
+                              // first LDS-DMA is issued, after the prologue's DMAs are issued}
 };
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);

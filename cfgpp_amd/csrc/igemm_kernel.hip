@@ -31,11 +31,11 @@ namespace {
 
 // diagnostics: wave 0 / lane 0 of a workgroup stamps slot `slot` of its timeline record (IGemmArgs::tl, normally null)
 __device__ __forceinline__ void tl_stamp(unsigned long long* tl, int slot) {
-    if (tl != nullptr && threadIdx.x == 0) tl[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+    if (tl != nullptr && threadIdx.x == 0) tl[(long)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
 }
 __device__ __forceinline__ void tl_begin(unsigned long long* tl) {
     if (tl != nullptr && threadIdx.x == 0) {
-        unsigned long long* r = tl + (long)blockIdx.x * 8;
+        unsigned long long* r = tl + (long)blockIdx.x * 16;
         r[0] = __builtin_amdgcn_s_memtime();
         r[4] = __builtin_amdgcn_s_memrealtime();
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -46,7 +46,7 @@ __device__ __forceinline__ void tl_end(unsigned long long* tl) {
     if (tl != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores have left
         if (threadIdx.x == 0) {
-            unsigned long long* r = tl + (long)blockIdx.x * 8;
+            unsigned long long* r = tl + (long)blockIdx.x * 16;
             r[3] = __builtin_amdgcn_s_memtime();
             r[5] = __builtin_amdgcn_s_memrealtime();
         }
@@ -195,6 +195,23 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
             if (p.omode == 1) opix = pp;
             if (p.rmode == 1) rpix = pp;
         }
+        // (register budget permitting) the residual pieces of this 32-row slab are requested BEFORE the transpose through
+        // LDS, so their latency runs under the bias / convert / staging work instead of after it
+        constexpr bool PREFETCH = NQ * 4 + MT * NT * 16 <= 176;
+        half8_t rres[PREFETCH ? NQ : 1];
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = lane + 64 * q;
+                const int r = c / CPR, cc = c - r * CPR;
+                const int rp = __shfl(rpix, r);
+                const int mm = mw0 + i * 32 + r, n = nw0 + cc * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) rres[q][k] = (half_t)0.f;
+                if (p.resid && c < 32 * CPR && mm < p.M && n < p.N)
+                    rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -227,7 +244,9 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
             if (c < 32 * CPR && mm < p.M && n < p.N) {
                 half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
                 if (p.resid) {
-                    const half8_t rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+                    half8_t rr;
+                    if constexpr (PREFETCH) rr = rres[q];
+                    else rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
                 }
@@ -562,8 +581,10 @@ igemm_kernel(const IGemmArgs p) {
         // are in flight / landed; a tile has NST-1 tile times to arrive (memory latency under load is of the
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
+        tl_stamp(p.tl, 8);
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
+        tl_stamp(p.tl, 9);
         if (NST > 2 && nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");   // NST-1 tiles issued: the oldest has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -854,6 +875,33 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
     constexpr int WTN = 80, PITCH = WTN * 2 + 16, CPR = WTN / 8, NQ = (32 * CPR + 63) / 64;
     const int c16 = lane & 15, fq = lane >> 4;
     const int HW = p.rows_per_batch;
+    // rows leave as 16-byte pieces; lane r (< 32) knows row r's output / residual pixel index
+    const int frow = lane & 31;
+    const int mr = mw0 + frow;
+    const int mrc = mr < p.M ? mr : p.M - 1;
+    int opix = mrc, rpix = mrc;
+    if (p.omode == 1 || p.rmode == 1) {
+        const int pp = padded_pix(mrc, HW, p.W, p.H);
+        if (p.omode == 1) opix = pp;
+        if (p.rmode == 1) rpix = pp;
+    }
+    // the residual pieces this lane will add are requested FIRST: their latency (HBM / Infinity Cache under load) runs
+    // under the bias / convert / LDS-transpose work below instead of after it
+    half8_t rres[NQ];
+    long ooff[NQ];
+    bool live[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int c = lane + 64 * q;
+        const int r = c / CPR, cc = c - r * CPR;
+        const int op = __shfl(opix, r), rp = __shfl(rpix, r);
+        const int mm = mw0 + r, n = nw0 + cc * 8;
+        live[q] = c < 32 * CPR && mm < p.M && n < p.N;
+        ooff[q] = (long)op * p.old + n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rres[q][k] = (half_t)0.f;
+        if (live[q] && p.resid) rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mw0 + i * 16 + c16;
@@ -881,30 +929,17 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
             *reinterpret_cast<half4_t*>(stg + (i * 16 + c16) * PITCH + nl * 2) = o;
         }
     }
-    // rows leave as 16-byte pieces; lane r (< 32) knows row r's output / residual pixel index
-    const int frow = lane & 31;
-    const int mr = mw0 + frow;
-    const int mrc = mr < p.M ? mr : p.M - 1;
-    int opix = mrc, rpix = mrc;
-    if (p.omode == 1 || p.rmode == 1) {
-        const int pp = padded_pix(mrc, HW, p.W, p.H);
-        if (p.omode == 1) opix = pp;
-        if (p.rmode == 1) rpix = pp;
-    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = lane + 64 * q;
         const int r = c / CPR, cc = c - r * CPR;
-        const int op = __shfl(opix, r), rp = __shfl(rpix, r);
-        const int mm = mw0 + r, n = nw0 + cc * 8;
-        if (c < 32 * CPR && mm < p.M && n < p.N) {
+        if (live[q]) {
             half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
             if (p.resid) {
-                const half8_t rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
+                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
             }
-            *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
+            *reinterpret_cast<half8_t*>(p.out + ooff[q]) = v;
         }
     }
 }
@@ -1089,6 +1124,7 @@ igemm16_kernel(const IGemmArgs p) {
     const int b_rd = (wn * 80 + c16) * 128;
 
     const int nk = p.K >> 6;
+    tl_stamp(p.tl, 8);
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1097,6 +1133,7 @@ igemm16_kernel(const IGemmArgs p) {
             for (int q = 0; q < 4; ++q) piece(q, s_, s_, g);
             if (b3) piece(4, s_, s_, g);
         }
+    tl_stamp(p.tl, 9);
     if (nk >= NST - 1) CFGPP_WAIT_TILES(NST - 2);      // NST-1 tiles issued: the oldest has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

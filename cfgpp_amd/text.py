@@ -42,6 +42,10 @@ class HipClipTextTower:
             state_dict = load_safetensors_iter(state_dict)
         items = state_dict.items() if isinstance(state_dict, dict) else state_dict
         for k, v in items:
+            # checkpoint files (and transformers 4.x modules) prefix the tower's tensors with "text_model."; the bare
+            # CLIPTextModel of transformers 5.x does not
+            if not k.startswith("text_model.") and k != "text_projection.weight":
+                k = "text_model." + k
             if k.endswith("position_ids") or (k == "text_projection.weight" and not self.proj):
                 continue
             t = v.detach().cpu().contiguous()

@@ -278,9 +278,9 @@ void cfgpp_igemm_set_big_tiles(int on);  /* 1 = allow the 8-wave 256x256 / 256x3
 void cfgpp_igemm_set_staged_epilogue(int on); /* 1 = LDS-transposed row-coalesced store epilogue (default) */
 void cfgpp_igemm_set_staging(int glds);   /* 1 = global_load_lds tiles (default), 0 = register staging */
 /* diagnostics: per-workgroup timeline of ONE implicit-GEMM launch.  Arms the `target`-th launch (0-based) after this call:
- * every workgroup writes 8 x uint64 into buf[grid][8] (device memory, cap_blocks records): s_memtime at {entry, first
+ * every workgroup writes 16 x uint64 into buf[grid][16] (device memory, cap_blocks records): s_memtime at {entry, first
  * K-tile landed, k-loop done, stores done}, s_memrealtime (100 MHz) at {entry, exit}, HW_ID | XCC_ID << 32, s_memtime after
- * the first K-tile.  buf = NULL disarms.  cfgpp_igemm_timeline_info: {tile id, grid, threads, BM, BN, LDS stages, K-split,
+ * the first K-tile, s_memtime {before the first LDS-DMA is issued, after the prologue's DMAs are issued}.  buf = NULL disarms.  cfgpp_igemm_timeline_info: {tile id, grid, threads, BM, BN, LDS stages, K-split,
  * N-major walk, M, N, K, epilogue} of the recorded launch (scripts/igemm_timeline.py). */
 void cfgpp_igemm_timeline(void* buf, long cap_blocks, int target);
 void cfgpp_igemm_timeline_info(int* out12);

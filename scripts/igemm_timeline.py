@@ -37,7 +37,7 @@ for i, kind, desc, us, gf in detail:
         ordinal.setdefault(desc, k); k += 1
         times.setdefault(desc, []).append(float(us))
 CAP = 8192
-buf = torch.zeros((CAP, 8), dtype=torch.int64, device="cuda")
+buf = torch.zeros((CAP, 16), dtype=torch.int64, device="cuda")
 info = (C.c_int * 12)()
 
 
@@ -63,7 +63,7 @@ for want in wanted:
     if not ok.any():
         print(f"## {desc}: nothing recorded (grid {grid})"); continue
     r = r[ok]
-    t0, t1, t2, t3, rt0, rt1, t7 = r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 5], r[:, 7]
+    t0, t1, t2, t3, rt0, rt1, t7, t8, t9 = r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 5], r[:, 7], r[:, 8], r[:, 9]
     ghz = float(np.median((t3 - t0) / np.maximum(rt1 - rt0, 1))) * 0.1          # memtime ticks per 10 ns
     span_us = (rt1.max() - rt0.min()) * 0.01
     nk = (K // 64) // max(ksplit, 1)
@@ -77,7 +77,8 @@ for want in wanted:
     print(f"   clock ~{ghz:.2f} GHz; span first entry -> last exit {span_us:.1f} us = {flops / span_us / 1e6:.0f} TF/s; MFMA floor/K-tile "
           f"{BM * BN * 64 * 2 / (2.5e15 / 256) * 2.4e9:.0f} cyc @2.4GHz-peak")
     print(f"   start skew (us after first entry): p50 {pct((rt0 - rt0.min()) * 0.01, 50):.2f} p90 {pct((rt0 - rt0.min()) * 0.01, 90):.2f} max {((rt0 - rt0.min()) * 0.01).max():.2f}")
-    for nm, a in (("prologue (entry -> first tile landed)", pro), ("first K-tile", first), ("per K-tile (steady)", per_tile), ("K loop total", loop),
+    for nm, a in (("  entry -> first DMA issue (kernargs, index math)", t8 - t0), ("  issuing the prologue's DMAs", t9 - t8), ("  issued -> first tile landed", t1 - t9),
+                  ("prologue (entry -> first tile landed)", pro), ("first K-tile", first), ("per K-tile (steady)", per_tile), ("K loop total", loop),
                   ("epilogue (-> stores done)", epi_c), ("workgroup total", tot)):
-        print(f"   {nm:40s} cycles p10 {pct(a, 10):9.0f}  p50 {pct(a, 50):9.0f}  p90 {pct(a, 90):9.0f}  max {a.max():9.0f}   (p50 = {pct(a, 50) / ghz / 1e3:.2f} us)")
+        print(f"   {nm:50s} cycles p10 {pct(a, 10):9.0f}  p50 {pct(a, 50):9.0f}  p90 {pct(a, 90):9.0f}  max {a.max():9.0f}   (p50 = {pct(a, 50) / ghz / 1e3:.2f} us)")
     print(f"   workgroups per XCC id: {np.bincount(xcc.astype(np.int64), minlength=8).tolist()}")
