@@ -24,7 +24,9 @@ import sys
 import time
 import types
 
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as cfgpp_amd/__init__.py (must precede the first HIP call)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

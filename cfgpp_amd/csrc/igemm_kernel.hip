@@ -866,8 +866,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 //     16-lane groups of a ds_read_b128 hit 16 distinct bank quads (same argument as the 32-row case);
 //   * 8 waves x 8 rows = 64 rows per loader pass: 128 activation rows = 2 passes, 160 weight rows = 2 passes + one that
 //     only waves 0-3 take, so the counted vmcnt waits use the WAVE's piece count (5 or 4 per K-tile);
-//   * plain-store epilogue (bias / temb / residual through the per-wave LDS transpose) and a head-major one (switched off until
-//     it has run on hardware: cfgpp_igemm_set_mf16_heads); whole tiles only (no K-split).
+//   * plain-store epilogue (bias / temb / residual through the per-wave LDS transpose) and a head-major one
+//     (cfgpp_igemm_set_mf16_heads); whole tiles only (no K-split).
 // The 16 x 16 x 32 MFMA sums k in a different order than the 32 x 32 x 16 one, so this tile is NOT a tuner candidate (the
 // tuner's choices must not change results): it is used by rule (igemm_launch; cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
 __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
@@ -1140,56 +1140,74 @@ igemm16_kernel(const IGemmArgs p) {
     asm volatile("" ::: "memory");
     tl_stamp(p.tl, 1);
 
+    // K-tile schedule (round 3; the timeline of round 2's loop showed ~1300-1450 cycles per K-tile against an MFMA floor of
+    // 644: after every end-of-tile barrier all 8 waves first read BOTH k-steps' fragments (112 KB through the LDS pipe,
+    // nothing for the matrix pipe to do), and the two waves of a SIMD reached their LDS-DMA instructions - ~170 cycles of
+    // issue each at this rate - together):
+    //   * the barrier sits in the MIDDLE of a tile.  Phase 0 = the k-step-0 MFMAs of tile kt, whose fragments were read
+    //     during phase 1 of tile kt-1; phase 1 = the k-step-1 MFMAs, fragments read during phase 0.  Every fragment read has
+    //     ten MFMAs (~340 cycles) to land and is issued right AFTER the first MFMA of a phase, so the wait the compiler
+    //     puts in front of that MFMA cannot cover it.
+    //   * "tile kt+1 has landed" is waited for before that mid-tile barrier; the k-step-0 fragments of tile kt+1 are read
+    //     behind it.  A stage is free again once the barrier after its last reads has been passed, which is still before
+    //     the first DMA into it.
+    //   * the waves 0-3 (one per SIMD) issue their DMA pieces of tile kt+NST-1 during phase 0, their SIMD partners 4-7
+    //     during phase 1: while one wave of a SIMD sits in the memory pipe's queue the other one feeds the matrix pipe.
+    //     (waves 4-7 therefore have one tile less in flight at the barrier: their counted wait is one tile shorter.)
+    half8_t xa[2][2], wb[2][5];
+    auto rd_frags = [&](int s, int stage) {
+        const char* As = smem + stage * STAGE_BYTES;
+        const char* Bs = As + BM * 128;
+        const int coff = (((s << 2) | fq) ^ fsw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xa[s][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 16 * 128 + coff);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wb[s][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 16 * 128 + coff);
+    };
+    rd_frags(0, 0);
+
     auto tile_body = [&](int kt, int cur, int ktn, int nxt, auto with_dma) {
         constexpr bool DMA = decltype(with_dma)::value;
-        const char* As = smem + cur * STAGE_BYTES;
-        const char* Bs = As + BM * 128;
         Gather gn = {p.a0, 0, p.C0, 0, 0, 0};
         if constexpr (DMA) gn = gather_of(ktn);
-        // the next tile's pieces go out one by one during the first 5/8 of the MFMAs (igemm_kernel's interleave)
-        constexpr int NP = 5, SPAN = (NM * 5) / 8;
-        int issued = 0, done = 0;                        // compile-time after unrolling
-        auto after_mfma = [&]() {
-            ++done;
-            if constexpr (DMA) {
-                if (issued < NP && done * NP >= (issued + 1) * SPAN) {
+        // phase s: ten MFMAs; after the first one the fragments of the NEXT phase are requested; the wave's DMA pieces go out
+        // after every second MFMA of ITS phase
+        auto phase = [&](auto s_tag) {
+            constexpr int s = decltype(s_tag)::value;
+            const bool mine = (s == 0) == b3;
+#pragma unroll
+            for (int m = 0; m < 10; ++m) {
+                const int i = m / 5, j = m - 5 * (m / 5);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
+                if (m == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (issued < 4 || b3) piece(issued, ktn, nxt, gn);
-                    ++issued;
+                    if (s == 0) rd_frags(1, cur);
+                    else if (kt + 1 < nk) rd_frags(0, (kt + 1) % NST);
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (DMA) {
+                    if ((m & 1) == 1) {
+                        const int q = m >> 1;                        // 0 .. 4
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (mine && (q < 4 || b3)) piece(q, ktn, nxt, gn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         };
-        half8_t xa[2][2], wb[2][5];
-        {
-            const int coff = (fq ^ fsw) << 4;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xa[0][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 16 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) wb[0][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 16 * 128 + coff);
+        phase(std::integral_constant<int, 0>{});
+        // tile kt+1 has landed: waves 0-3 have issued up to tile kt+NST-1 (NST-2 younger tiles may be in flight), waves 4-7 up to
+        // kt+NST-2 (NST-3)
+        if constexpr (DMA) {
+            if (b3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * 5) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 3) * 4) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s == 0) {
-                const int coff = ((4 | fq) ^ fsw) << 4;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) xa[1][i] = *reinterpret_cast<const half8_t*>(As + a_rd + i * 16 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) wb[1][j] = *reinterpret_cast<const half8_t*>(Bs + b_rd + j * 16 * 128 + coff);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
-                    after_mfma();
-                }
-        }
-        if constexpr (DMA) CFGPP_WAIT_TILES(NST - 2);   // tile kt+1 has landed: only the younger tiles' pieces are outstanding
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        phase(std::integral_constant<int, 1>{});
     };
     int kt = 0;
     for (; kt + NST - 1 < nk; ++kt) {
@@ -1197,10 +1215,10 @@ igemm16_kernel(const IGemmArgs p) {
         if (kt == 0) tl_stamp(p.tl, 7);
     }
     for (; kt < nk; ++kt) tile_body(kt, kt % NST, 0, 0, std::false_type{});
+    // (the last mid-tile barrier was passed with vmcnt(0) and every LDS read complete: LDS is free for the epilogue)
     tl_stamp(p.tl, 2);
 #undef CFGPP_WAIT_TILES
 
-    // the k-loop ended with vmcnt(0) + barrier: LDS is free for the per-wave transposes
     if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536));
     else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
     tl_end(p.tl);
@@ -1294,7 +1312,8 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
 // forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
 // variant of the same tile (the LDS-DMA variant is the default)
 // 128 x 160 tile on 8 waves of 16x16x32 MFMAs (igemm16_kernel): whole tiles, plain-store epilogue
-static int g_mf16_heads = 0;           // 1: EPI_HEADS launches may use the tile too (head-major epilogue for the 16 x 16 layout)
+static int g_mf16_heads = 1;           // 1: EPI_HEADS launches may use the tile too (head-major epilogue for the 16 x 16 layout; first run
+                                       // on hardware in round 3: Q projection M = 4096 x N = 1280 432 -> 557 TF/s in situ)
 extern "C" void cfgpp_igemm_set_mf16_heads(int on) { g_mf16_heads = on ? 1 : 0; }
 static bool mf16_supports(const IGemmArgs& a) {
     if (a.N % 160 != 0 || !g_staged_epi || a.K < 64) return false;

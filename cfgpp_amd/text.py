@@ -1,9 +1,9 @@
 """CLIP text tower on libcfgpp_hip.so (``csrc/text.hip``): same call contract as ``conditioning.ClipTextTower`` -
 ``tower(prompts, clip_skip=None) -> (hidden [n,77,D] fp16, pooled [n,P] fp16 | None)`` - without torch ops.
 
-Opt-in (``get_solver(..., text_encoder=HipClipTextTower.from_dir(...))``); the default text path is unchanged.  The engine
-was written after the round's GPU budget was spent: its first contact with hardware is ``tests/test_gpu_text.py``
-(``CFGPP_TEST_TEXT=1``), which compares it with ``transformers.CLIPTextModel(WithProjection)`` on the same weights.
+Opt-in (``get_solver(..., text_encoder=HipClipTextTower.from_dir(...))``); the default text path is unchanged.
+``tests/test_gpu_text.py`` compares it with ``transformers.CLIPTextModel(WithProjection)`` on the same weights (CLIP-L and
+OpenCLIP-bigG widths, both activations, penultimate / clip_skip outputs, pooled projection).
 """
 from __future__ import annotations
 

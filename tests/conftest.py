@@ -1,7 +1,9 @@
 import os
 import sys
 
-import pytest
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as cfgpp_amd/__init__.py (must precede the first HIP call)
+
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):

@@ -313,15 +313,13 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
 @case("heads_projection_d40")
 def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
     """QKV projection at the SD1.5 level-0 geometry (N = 960 = 6 x 160, head dim 40: 16-column groups straddle heads): the
-    heuristic tile and the 4-wave 128x160 tile; with CFGPP_TEST_MF16_HEADS=1 also the 16x16x32-MFMA tile's head-major
-    epilogue (configs 18 / 19, switched off by default until it has run on hardware)."""
-    import os
+    heuristic tile, the 4-wave 128x160 tile and the 16x16x32-MFMA tile's head-major epilogue (configs 18 / 19)."""
     a = rnd(B * tokens, C, seed=46)
     w = rnd(3 * C, C, scale=C ** -0.5, seed=47)
     d = C // nheads
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
-    cfgs = [0, 7] + ([18, 19] if os.environ.get("CFGPP_TEST_MF16_HEADS") == "1" else [])
+    cfgs = [0, 7, 18, 19]
     out = {}
     H.lib().cfgpp_igemm_set_mf16_heads(1 if 18 in cfgs else 0)
     try:
@@ -333,7 +331,37 @@ def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
             out[f"vt_cfg{c}"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
     finally:
         H.lib().cfgpp_igemm_force_config(0)
-        H.lib().cfgpp_igemm_set_mf16_heads(0)
+        H.lib().cfgpp_igemm_set_mf16_heads(1)
+    return out
+
+
+@case("mf16_race")
+def t_mf16_race():
+    """igemm16_kernel at full-chip grids (256 tiles, 20 .. 180 K-tiles, 3- and 4-stage rings): repeated launches must be
+    bit-identical (an LDS race shows as run-to-run differences) and match fp32"""
+    out = {}
+    for name, M, N, K, conv in (("lin_k1280", 4096, 1280, 1280, False), ("lin_k5120", 4096, 1280, 5120, False), ("conv_k2880", 4096, 1280, 320, True)):
+        if conv:
+            x = rnd(4, 320, 32, 32, seed=70)
+            w = rnd(N, 320, 3, 3, scale=(9 * 320) ** -0.5, seed=71)
+            ref = F.conv2d(x, w, None, padding=1)
+            xp, wp = H.to_pn(x), H.pack_conv3(w)
+        else:
+            a = rnd(M, K, seed=72)
+            w = rnd(N, K, scale=K ** -0.5, seed=73)
+            res = rnd(M, N, seed=74)
+            ref = a @ w.t() + res
+            ad, wd, rd = a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), res.to(H.DEV, torch.float16)
+        for c in (18, 19):
+            H.lib().cfgpp_igemm_force_config(c)
+            runs = []
+            for _ in range(12):
+                if conv:
+                    runs.append(H.from_pn(H.conv3x3(xp, wp, None, 32, 32)))
+                else:
+                    runs.append(H.linear(ad, wd, None, resid=rd).float().cpu())
+            out[f"{name}_cfg{c}"] = dict(H.err_stats(runs[0], ref), identical_runs=all(torch.equal(runs[0], r_) for r_ in runs[1:]))
+    H.lib().cfgpp_igemm_force_config(0)
     return out
 
 

@@ -99,12 +99,16 @@ def test_heads_projection_scatter(diag):
 
 
 def test_heads_projection_head_dim_40_on_the_16x16x32_tile(diag):
-    """opt-in (CFGPP_TEST_MF16_HEADS=1): the head-major epilogue of igemm16_kernel is switched off and has not run on
-    hardware yet - this is its first-contact test (heuristic and 4-wave tiles at the same geometry as controls)"""
-    import os
-    if os.environ.get("CFGPP_TEST_MF16_HEADS") != "1":
-        pytest.skip("set CFGPP_TEST_MF16_HEADS=1 (unvalidated, switched-off code path)")
+    """QKV projection at the SD1.5 level-0 geometry (head dim 40: 16-column groups straddle heads) through the heuristic
+    tile, the 4-wave 128x160 tile and the head-major epilogue of igemm16_kernel (configs 18 / 19)"""
     _check(diag, diag.t_heads_d40, "heads_projection_d40")
+
+
+def test_16x16x32_tile_is_race_free_at_the_unet_sizes(diag):
+    """the mid-tile-barrier schedule of igemm16_kernel (fragment reads a half tile ahead, staggered LDS-DMA issue) at the
+    launch shapes it carries in the UNet: 12 repetitions bit-identical, and right against fp32"""
+    r = _check(diag, diag.t_mf16_race, "mf16_race")
+    assert all(v["identical_runs"] for v in r.values())
 
 
 def test_conv_in_out(diag):

@@ -40,7 +40,7 @@ def test_ddim_step_equals_torch_rocm_on_the_references_expressions(E, mode, z_ha
     from cfgpp_amd.coeffs import ddim_coeffs
     from cfgpp_amd.schedule import SchedulerTables
     tb = SchedulerTables(50)
-    alphas = torch.cat([torch.tensor([1.0]), tb.alphas_cumprod])          # latent_diffusion.py:81 (a CPU tensor)
+    alphas = tb.alphas_cumprod                   # the shifted table cat([1.0], abar) of latent_diffusion.py:81 (a CPU tensor)
     lam = 0.6 if "cfgpp" in mode else 7.5
     bad, detail = 0, []
     for k, t in enumerate([981, 501, 21]):
@@ -146,7 +146,7 @@ def test_device_resident_final_alpha(E, flow, z_half):
     from cfgpp_amd.coeffs import ddim_coeffs_pinned
     from cfgpp_amd.schedule import SchedulerTables
     tb = SchedulerTables(50)
-    alphas = torch.cat([torch.tensor([1.0]), tb.alphas_cumprod])
+    alphas = tb.alphas_cumprod                   # already the shifted table cat([1.0], abar)
     t = 1
     at = alphas[t]
     at_prev = tb.final_alpha_cumprod.clone().cuda()          # alpha(t - skip) for t - skip < 0
