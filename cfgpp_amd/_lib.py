@@ -78,6 +78,10 @@ PROTOTYPES = {
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "cfgpp_op_ln_stats": (_I, [_P, _P, _L, _I, _F, _P]),
+    "cfgpp_op_igemm_heads_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "cfgpp_op_geglu_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "cfgpp_unet_set_fuse_ln": (None, [_I]),
     "cfgpp_op_attention_prepare_vt": (_I, [_P, _I, _I, _I, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -108,6 +112,8 @@ PROTOTYPES = {
     "cfgpp_groupnorm_set_mode": (None, [_I]),
     "cfgpp_layernorm_set_rows_per_wave": (None, [_I]),
     "cfgpp_attention_set_dma": (None, [_I]),
+    "cfgpp_attention_set_stagger": (None, [_I]),
+    "cfgpp_attention_set_cross": (None, [_I]),
 }
 
 _lib = None

@@ -59,6 +59,21 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
     return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
 }
 
+// fused LayerNorm (IGemmArgs::ln_stats): (mean, rstd) of GEMM row m, or (0, 1) when the launch has none
+__device__ __forceinline__ float2 ln_row(const IGemmArgs& p, int m) {
+    if (p.ln_stats == nullptr) return make_float2(0.f, 1.f);
+    const int mc = m < p.M ? m : p.M - 1;
+    return *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mc);
+}
+// v[0..3] (columns n .. n+3 of a row with statistics st) <- rstd * (v - mean * c[n..])
+__device__ __forceinline__ void ln_apply4(const IGemmArgs& p, float (&v)[4], const float2 st, int n) {
+    if (p.ln_stats != nullptr) {
+        const float4 cc = *reinterpret_cast<const float4*>(p.ln_c + n);
+        v[0] = st.y * (v[0] - st.x * cc.x); v[1] = st.y * (v[1] - st.x * cc.y);
+        v[2] = st.y * (v[2] - st.x * cc.z); v[3] = st.y * (v[3] - st.x * cc.w);
+    }
+}
+
 // Shared epilogue.  lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
 template <int MT, int NT>
 __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane) {
@@ -70,6 +85,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         if (m >= p.M) continue;
         const int b = (HW > 0) ? m / HW : 0;
         const int tok = m - b * HW;
+        const float2 lnst = ln_row(p, m);
         long orow = m, rrow = m;
         if (p.omode == 1 || p.rmode == 1) {
             const long pp = padded_pix(m, HW, p.W, p.H);
@@ -120,6 +136,8 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                         float v[4], gt[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
+                        ln_apply4(p, v, lnst, pc);
+                        ln_apply4(p, gt, lnst, pc + 32);
                         if (p.bias) {
                             const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
                             const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
@@ -146,6 +164,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
+                    ln_apply4(p, v, lnst, n);
                     if (p.bias) {
                         const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -270,6 +289,7 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
     const int NF = p.N >> 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        const float2 lnst = ln_row(p, mw0 + i * 32 + frow);
 #pragma unroll
         for (int j = 0; j < NT; j += 2)
 #pragma unroll
@@ -279,6 +299,8 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
                 float v[4], gt[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
+                ln_apply4(p, v, lnst, pc);
+                ln_apply4(p, gt, lnst, pc + 32);
                 if (p.bias) {
                     const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
                     const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
@@ -321,6 +343,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
         const int m0s = mw0 + i * 32;                          // first token row of the sub-tile (multiple of 32)
         if (m0s >= p.M) continue;
         const int b = m0s / HW, tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
+        const float2 lnst = ln_row(p, m0s + frow);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ng = nw0 + j * 32;                       // first column of the 32-column group
@@ -333,6 +356,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
                 float v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
+                ln_apply4(p, v, lnst, n);
                 if (p.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -956,6 +980,9 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     const int c16 = lane & 15, fq = lane >> 4;
     const int HW = p.rows_per_batch;
     const int b = mw0 / HW, tok0 = mw0 - b * HW;               // one batch, one aligned 32-token block
+    float2 lnst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lnst[i] = ln_row(p, mw0 + i * 16 + c16);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ng = nw0 + j * 16;                           // first column of the 16-column group (ng < N: N % 160 == 0)
@@ -968,6 +995,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
+            ln_apply4(p, v, lnst[i], n);
             if (p.bias) {
                 const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -1410,7 +1438,10 @@ static int g_split_cfg = 14;
 extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
 static int g_mf16 = 4;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
 extern "C" void cfgpp_igemm_set_mf16(int mode) { g_mf16 = (mode == 3 || mode == 4) ? mode : 0; }
-static int g_mf16_rounds = 1;          // the rule also takes grids of exactly 2 .. n full rounds of 256 tiles (1 = one round only)
+static int g_mf16_rounds = 2;          // the rule also takes grids of exactly 2 .. n full rounds of 256 tiles (1 = one round only).  Two rounds
+                                       // = the M = 16384 x N = 640 class (32x32 level of SD1.5 at batch 8, 64x64 level of SDXL at batch 2): convs
+                                       // 743 -> 860, 810 -> 954 TF/s in situ with the round-3 K-tile schedule (profiles/r03/ab/mf16_rounds.txt);
+                                       // three rounds (QKV projection N = 3840 at M = 4096) lose against the 256 x 256 tile
 extern "C" void cfgpp_igemm_set_mf16_rounds(int n) { g_mf16_rounds = n >= 1 ? n : 1; }
 static int g_force_split = 0;          // diagnostics: with a forced config, K-split every tile this many ways
 extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0; }
@@ -1445,6 +1476,8 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.amode != 3 || (a.H < 2048 && a.W < 2048 && (a.M / a.rows_per_batch) < 512), "igemm: upsample range");
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
+    CFGPP_REQUIRE(a.ln_stats == nullptr || (a.ln_c != nullptr && a.epi != EPI_STORE && a.amode == 0),
+                  "igemm: the fused LayerNorm needs ln_c and a token-major EPI_HEADS / EPI_GEGLU launch");
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for
     // N = 64*odd (e.g. 320), 64x64 (4 waves of 32x32) for small problems.
     int cfg = g_force_cfg;

@@ -200,6 +200,9 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
 /* development / A-B switch of the GroupNorm form: 0 auto, 1 always the two-launch form, 2 the one-launch
  * slab-in-registers kernel whenever the slab fits (csrc/norm_kernels.hip). */
 void cfgpp_groupnorm_set_mode(int mode);
+/* LayerNorm statistics only: stats[row] = (mean, rstd) fp32, exact two-pass variance; the projection that consumes the
+ * LayerNorm applies it in its epilogue (cfgpp_op_linear_ln / cfgpp_op_igemm_heads_ln, and the UNet's transformer blocks) */
+int cfgpp_op_ln_stats(const void* x, float* stats, long rows, int C, float eps, void* stream);
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream);
 /* development / A-B switch: token rows each wave of the LayerNorm kernel keeps in flight (0 = by row count, 1 / 2 / 4);
@@ -214,6 +217,12 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
 /* A/B switch for head dims padded to 64: 1 (default) the LDS-DMA kernel, 0 the register-staged kernel */
 void cfgpp_attention_set_dma(int mode);
+/* A/B knob of the LDS-DMA attention kernel: the workgroups sharing a CU start `sleeps` x 64 cycles apart per dispatch slot
+ * (0 = together, the default) so that their QK^T / softmax / PV phases interleave instead of coinciding */
+void cfgpp_attention_set_stagger(int sleeps);
+/* A/B switch: 1 (default) attention with <= 128 keys and head dims padded to 64 (the 77-token cross-attention) runs the
+ * resident-K/V single-pass kernel, 0 the flash loop */
+void cfgpp_attention_set_cross(int on);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                      int R, int zB, int Cin, int H, int W, int Cout, void* stream);
 /* quant_conv (1x1, 8->8) + DiagonalGaussian posterior on the encoder's 8-channel conv_out (fp32 NCHW). */
@@ -244,6 +253,18 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
+/* the head-major projection / the GEGLU projection with a LayerNorm of the input rows folded in: a = UN-normalised rows,
+ * w = W * gamma (per input channel), bias = W beta (+ the layer's bias), ln_c[n] = sum_k w[n][k], ln_stats = (mean, rstd) per
+ * row from cfgpp_op_ln_stats; the epilogue forms rstd * (acc - mean * ln_c) + bias.  Same output contracts as
+ * cfgpp_op_igemm_heads / cfgpp_op_igemm with epi = 1 (w and bias in the packed GEGLU order). */
+int cfgpp_op_igemm_heads_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
+                            const float* ln_c, int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width,
+                            int head_dim, int heads, int q_tok_pad, int tok_pad, void* stream);
+int cfgpp_op_geglu_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
+                      const float* ln_c, void* out, void* stream);
+/* 1 (default): UNet engines finalized after this call fold the transformer blocks' LayerNorms into the projections that
+ * consume them; 0: separate layernorm launches (A/B, fallback) */
+void cfgpp_unet_set_fuse_ln(int on);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
  * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);

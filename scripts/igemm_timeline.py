@@ -18,8 +18,8 @@ from cfgpp_amd.hip_engine import HipEngine  # noqa: E402
 name, rows = sys.argv[1], int(sys.argv[2])
 wanted = sys.argv[3:]
 lib = _lib.load()
-lib.cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "0")))
-lib.cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "1")))
+lib.cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))
+lib.cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))
 eng = HipEngine(name, max_batch=rows // 2)
 cfg, B = eng.cfg, rows // 2
 uc = torch.randn(1, 77, cfg.cross_attention_dim).half() * 0.5; c = torch.randn(B, 77, cfg.cross_attention_dim).half() * 0.5

@@ -15,6 +15,8 @@ if d % 32: hq[:, :, d:] = 0; hk[:, :, d:] = 0; hvt[:, d:, :] = 0
 _lib.check(H.lib().cfgpp_op_attention_prepare_vt(H.P(hvt), B * h, d, kp, H.stream()), "prep")
 o = torch.empty(B, N, h * d, device="cuda", dtype=torch.float16)
 H.lib().cfgpp_attention_set_dma(int(os.environ.get("ATTN_MODE", "1")))
+H.lib().cfgpp_attention_set_stagger(int(os.environ.get("ATTN_STAGGER", "0")))
+H.lib().cfgpp_attention_set_cross(int(os.environ.get("ATTN_CROSS", "1")))
 fn = lambda: _lib.check(H.lib().cfgpp_op_attention(H.P(hq), H.P(hk), H.P(hvt), H.P(o), B, h, d, N, Nk, qp, kp, H.stream()), "attn")
 for _ in range(3): fn()
 torch.cuda.synchronize(); s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,4 +24,4 @@ s.record()
 for _ in range(iters): fn()
 e.record(); torch.cuda.synchronize()
 dt = s.elapsed_time(e) / iters * 1e-3
-print(f"attn B={B} h={h} N={N} Nk={Nk} d={d}: {dt*1e6:.1f} us  {4.0*B*h*N*Nk*d/dt/1e12:.1f} TF/s", flush=True)
+print(f"attn B={B} h={h} N={N} Nk={Nk} d={d} mode={os.environ.get('ATTN_MODE', '1')} stagger={os.environ.get('ATTN_STAGGER', '0')} cross={os.environ.get('ATTN_CROSS', '1')}: {dt*1e6:.1f} us  {4.0*B*h*N*Nk*d/dt/1e12:.1f} TF/s", flush=True)

@@ -14,10 +14,14 @@ _lib.load().cfgpp_igemm_set_autotune(int(os.environ.get("AUTOTUNE", "1")))
 _lib.load().cfgpp_igemm_set_tune_mask(int(os.environ.get("TUNE_MASK", "0xffffffff"), 0))
 _lib.load().cfgpp_igemm_set_big_split(int(os.environ.get("BIG_SPLIT", "0")))
 _lib.load().cfgpp_layernorm_set_rows_per_wave(int(os.environ.get("LN_RPW", "0")))
-_lib.load().cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "0")))       # 1: head-major epilogue of that tile (unvalidated)
-_lib.load().cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "1")))     # > 1: also 2 .. n full rounds of 256 tiles
+_lib.load().cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))       # 1: head-major epilogue of that tile (unvalidated)
+_lib.load().cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))     # > 1: also 2 .. n full rounds of 256 tiles
 _lib.load().cfgpp_igemm_set_mf16(int(os.environ.get("MF16", "4")))                 # 3 / 4: 16x16x32-MFMA 128x160 tile by rule
 _lib.load().cfgpp_igemm_set_split_tile(int(os.environ.get("SPLIT_TILE", "14")))
+_lib.load().cfgpp_attention_set_stagger(int(os.environ.get("ATTN_STAGGER", "0")))
+_lib.load().cfgpp_unet_set_fuse_ln(int(os.environ.get("FUSE_LN", "1")))
+_lib.load().cfgpp_attention_set_cross(int(os.environ.get("ATTN_CROSS", "1")))
+_lib.load().cfgpp_attention_set_dma(int(os.environ.get("ATTN_MODE", "1")))
 _lib.load().cfgpp_igemm_set_tail_split(int(os.environ.get("TAIL_SPLIT", "1")))      # 2 = round-1 slice count (rounded up)
 eng = HipEngine(name, max_batch=rows // 2, latent_hw=(hw, hw) if hw else None)
 cfg = eng.cfg
