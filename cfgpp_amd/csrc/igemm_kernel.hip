@@ -65,18 +65,87 @@ __device__ __forceinline__ float2 ln_row(const IGemmArgs& p, int m) {
     const int mc = m < p.M ? m : p.M - 1;
     return *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mc);
 }
+
+// ---- epilogue parameters in LDS -----------------------------------------------------------------------------------------
+// The per-column parameters of an epilogue (bias, per-batch time embedding, LayerNorm column sums) used to be read from
+// global memory where they are consumed: one 16-byte load per 4 columns, each inside its own `if (p.bias)` block and therefore
+// followed by its own s_waitcnt vmcnt(0) - 25 (128x160 tile) to 60 (256x320 tile) serialised memory round trips per
+// workgroup, 10-40 thousand cycles: the round-3 timelines show the epilogues costing 5-22 us per workgroup for that reason,
+// not for bandwidth.  Now the tile's BN-column segments of those vectors go HBM -> LDS by LDS-DMA (4 bytes per lane) as the
+// FIRST loads of the kernel: they are older than every K-tile piece, so the counted vmcnt of the K loop covers them, the
+// K loop's barriers publish them, and the epilogue reads them with ds_read_b128.
+constexpr int PAR_NB = 5;                                  // time-embedding rows (batches) staged per tile: BM <= 256, H*W >= 64
+__host__ __device__ constexpr int par_bnp(int BN) { return (BN + 63) / 64 * 64; }
+__host__ __device__ constexpr int par_bytes(int BN) { return par_bnp(BN) * 4 * (2 + PAR_NB); }
+struct Par {
+    const char* lds;     // null: read the parameters from global memory (register-staged kernels, the K-split reduce kernel)
+    int n0, b0, bnp;     // first column / first batch of the tile, padded segment length (floats)
+};
+// issue the DMA pieces (64 floats each) of the tile's parameter segments; NW = waves of the workgroup
+template <int BN, int NW>
+__device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0, int m0, int wid, int lane) {
+    constexpr int BNP = par_bnp(BN), NPC = BNP / 64;
+    int nn = n0 + lane;                                     // + 64 * piece, clamped per piece
+    const int HW = p.rows_per_batch;
+    const int b0 = HW > 0 ? m0 / HW : 0;
+    const int nb = HW > 0 ? (p.M + HW - 1) / HW : 1;
+    int pi = 0;                                             // running piece index -> wave pi % NW (compile-time after unrolling)
+    auto arr = [&](const float* src, int slot) {
+#pragma unroll
+        for (int q = 0; q < NPC; ++q, ++pi) {
+            if (wid == pi % NW) {
+                int n = nn + 64 * q;
+                n = n < p.N ? n : p.N - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + n),
+                                                 (__attribute__((address_space(3))) void*)(par + (slot * BNP + q * 64) * 4), 4, 0, 0);
+            }
+        }
+    };
+    if (p.bias) arr(p.bias, 0);
+    if (p.ln_stats) arr(p.ln_c, 1);
+    if (p.temb) {
+#pragma unroll
+        for (int k = 0; k < PAR_NB; ++k) {
+            int b = b0 + k;
+            b = b < nb ? b : nb - 1;
+            arr(p.temb + (long)b * p.temb_ld, 2 + k);
+        }
+    }
+}
+// L = the kernel staged the segments in LDS (compile-time: a run-time choice kept a global-load path with its waits alive)
+template <bool L>
+__device__ __forceinline__ float4 par_bias4(const IGemmArgs& p, const Par& q, int n) {
+    if constexpr (L) return *reinterpret_cast<const float4*>(q.lds + (n - q.n0) * 4);
+    else return *reinterpret_cast<const float4*>(p.bias + n);
+}
+template <bool L>
+__device__ __forceinline__ float4 par_lnc4(const IGemmArgs& p, const Par& q, int n) {
+    if constexpr (L) return *reinterpret_cast<const float4*>(q.lds + (q.bnp + n - q.n0) * 4);
+    else return *reinterpret_cast<const float4*>(p.ln_c + n);
+}
+template <bool L>
+__device__ __forceinline__ float4 par_temb4(const IGemmArgs& p, const Par& q, int b, int n) {
+    if constexpr (L) {
+        int k = b - q.b0;                              // < PAR_NB: igemm_launch requires H*W >= 64 for launches with a time embedding
+        k = k < PAR_NB ? k : PAR_NB - 1;
+        return *reinterpret_cast<const float4*>(q.lds + ((2 + k) * q.bnp + n - q.n0) * 4);
+    } else {
+        return *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+    }
+}
 // v[0..3] (columns n .. n+3 of a row with statistics st) <- rstd * (v - mean * c[n..])
-__device__ __forceinline__ void ln_apply4(const IGemmArgs& p, float (&v)[4], const float2 st, int n) {
+template <bool L>
+__device__ __forceinline__ void ln_apply4(const IGemmArgs& p, const Par& q, float (&v)[4], const float2 st, int n) {
     if (p.ln_stats != nullptr) {
-        const float4 cc = *reinterpret_cast<const float4*>(p.ln_c + n);
+        const float4 cc = par_lnc4<L>(p, q, n);
         v[0] = st.y * (v[0] - st.x * cc.x); v[1] = st.y * (v[1] - st.x * cc.y);
         v[2] = st.y * (v[2] - st.x * cc.z); v[3] = st.y * (v[3] - st.x * cc.w);
     }
 }
 
 // Shared epilogue.  lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
-template <int MT, int NT>
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane) {
+template <int MT, int NT, bool L>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane, const Par& par) {
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
 #pragma unroll
@@ -106,11 +175,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * p.out_scale;
                     if (p.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        const float4 bb = par_bias4<L>(p, par, n);
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                     }
                     if (p.temb) {
-                        const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+                        const float4 tt = par_temb4<L>(p, par, b, n);
                         v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
                     }
                     if (p.resid) {
@@ -136,11 +205,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                         float v[4], gt[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
-                        ln_apply4(p, v, lnst, pc);
-                        ln_apply4(p, gt, lnst, pc + 32);
+                        ln_apply4<L>(p, par, v, lnst, pc);
+                        ln_apply4<L>(p, par, gt, lnst, pc + 32);
                         if (p.bias) {
-                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
-                            const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
+                            const float4 bv = par_bias4<L>(p, par, pc);
+                            const float4 bg = par_bias4<L>(p, par, pc + 32);
                             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                             gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                         }
@@ -164,9 +233,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
-                    ln_apply4(p, v, lnst, n);
+                    ln_apply4<L>(p, par, v, lnst, n);
                     if (p.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        const float4 bb = par_bias4<L>(p, par, n);
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                     }
                     const long bh = (long)b * p.heads + head;
@@ -193,13 +262,18 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
 // row segments (WTN*2 bytes contiguous, 16 B per lane): coalesced residual loads and output stores.
 // bias / time-embedding are added in fp32 before the (single) rounding to fp16; the residual is added to
 // the fp16 value, which is exactly the reference's `conv(...)` (fp16) `+ residual` (fp16) order.
-template <int MT, int NT>
+template <int MT, int NT, bool L>
 __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
-                                                      char* stg /* wave-private, 32 * (NT*64 + 16) bytes */) {
+                                                      char* stg /* wave-private, 32 * (NT*64 + 16) bytes */, const Par& par) {
     constexpr int WTN = NT * 32;
     constexpr int PITCH = WTN * 2 + 16;
     constexpr int CPR = WTN / 8;                 // 16-B chunks per row
     constexpr int NQ = (32 * CPR + 63) / 64;
+    // the residual pieces of a 32-row slab are requested in ONE block of loads (clamped addresses, no per-piece branch: a
+    // branch per piece made every load wait for itself), BEHIND the transpose through LDS: every read of the parameter
+    // segments carries a compiler-inserted vmcnt(0) (they were written by LDS-DMA), which is free only while no other load is
+    // in flight.  One memory latency per 32-row slab stays exposed.
+    constexpr bool EARLY = false;
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
 #pragma unroll
@@ -214,23 +288,19 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
             if (p.omode == 1) opix = pp;
             if (p.rmode == 1) rpix = pp;
         }
-        // (register budget permitting) the residual pieces of this 32-row slab are requested BEFORE the transpose through
-        // LDS, so their latency runs under the bias / convert / staging work instead of after it
-        constexpr bool PREFETCH = NQ * 4 + MT * NT * 16 <= 176;
-        half8_t rres[PREFETCH ? NQ : 1];
-        if constexpr (PREFETCH) {
+        half8_t rres[NQ];
+        auto request_residual = [&]() {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = lane + 64 * q;
                 const int r = c / CPR, cc = c - r * CPR;
-                const int rp = __shfl(rpix, r);
-                const int mm = mw0 + i * 32 + r, n = nw0 + cc * 8;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) rres[q][k] = (half_t)0.f;
-                if (p.resid && c < 32 * CPR && mm < p.M && n < p.N)
-                    rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+                const int rp = __shfl(rpix, r);                 // (rows >= 32 of a padded last pass wrap to a valid row)
+                int n = nw0 + cc * 8;
+                n = n < p.N ? n : p.N - 8;
+                rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
             }
-        }
+        };
+        if constexpr (EARLY) { if (p.resid) request_residual(); }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -242,11 +312,11 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k] * p.out_scale;
                 if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float4 bb = par_bias4<L>(p, par, n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                 }
                 if (p.temb) {
-                    const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
+                    const float4 tt = par_temb4<L>(p, par, b, n);
                     v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
                 }
                 half4_t o;
@@ -254,32 +324,28 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
                 for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
                 *reinterpret_cast<half4_t*>(stg + frow * PITCH + nl * 2) = o;
             }
+        if constexpr (!EARLY) { if (p.resid) request_residual(); }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c = lane + 64 * q;
             const int r = c / CPR, cc = c - r * CPR;
-            const int op = __shfl(opix, r), rp = __shfl(rpix, r);        // row r's pixel indices (lane r holds row r)
+            const int op = __shfl(opix, r);                      // row r's output pixel index (lane r holds row r)
             const int mm = mw0 + i * 32 + r, n = nw0 + cc * 8;
-            if (c < 32 * CPR && mm < p.M && n < p.N) {
-                half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
-                if (p.resid) {
-                    half8_t rr;
-                    if constexpr (PREFETCH) rr = rres[q];
-                    else rr = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+            half8_t v = *reinterpret_cast<const half8_t*>(stg + (r & 31) * PITCH + cc * 16);
+            if (p.resid) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rr[k]);
-                }
-                *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
+                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
             }
+            if (c < 32 * CPR && mm < p.M && n < p.N) *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
         }
     }
 }
 
 // GEGLU through LDS: value tile j and gate tile j+1 of a wave hold the same 32 features; the product
 // v * gelu(g) is staged as [32 rows][NT/2*32 features] and written as row segments (16 B per lane).
-template <int MT, int NT>
+template <int MT, int NT, bool L>
 __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
-                                                            char* stg) {
+                                                            char* stg, const Par& par) {
     constexpr int WTF = (NT / 2) * 32;            // output features per wave
     constexpr int PITCH = WTF * 2 + 16;
     constexpr int CPR = WTF / 8;
@@ -299,11 +365,11 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
                 float v[4], gt[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
-                ln_apply4(p, v, lnst, pc);
-                ln_apply4(p, gt, lnst, pc + 32);
+                ln_apply4<L>(p, par, v, lnst, pc);
+                ln_apply4<L>(p, par, gt, lnst, pc + 32);
                 if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + pc);
-                    const float4 bg = *reinterpret_cast<const float4*>(p.bias + pc + 32);
+                    const float4 bv = par_bias4<L>(p, par, pc);
+                    const float4 bg = par_bias4<L>(p, par, pc + 32);
                     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                     gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                 }
@@ -331,9 +397,9 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
 // leaves as 16-byte pieces: 8 consecutive head dims of one token (Q, K) or 8 consecutive key positions of one head
 // dim (V^T).  Needs rows_per_batch % 32 == 0 (a sub-tile then lies inside one batch and one 32-key block) and
 // part_width % 32 == 0, head_dim % 8 == 0 (a 32-column group has one part, a 16-byte piece one head).
-template <int MT, int NT>
+template <int MT, int NT, bool L>
 __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
-                                                            char* stg /* wave-private, NT * 2560 bytes */) {
+                                                            char* stg /* wave-private, NT * 2560 bytes */, const Par& par) {
     constexpr int PITCH = 80, BLK = 32 * PITCH;
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
@@ -356,9 +422,9 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
                 float v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
-                ln_apply4(p, v, lnst, n);
+                ln_apply4<L>(p, par, v, lnst, n);
                 if (p.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float4 bb = par_bias4<L>(p, par, n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
                 }
                 if (part == 2 && !p.vt_linear) {               // transposed: [head dim column][key position]
@@ -425,6 +491,7 @@ igemm_kernel(const IGemmArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     tl_begin(p.tl);
+    constexpr int PAR_OFF = NST * (WM * WTM + WN * WTN) * 128;       // epilogue parameters behind the ring (LDS-DMA kernels only)
 
     // ---- workgroup -> (tile, k-range).  Blocks [0, n_main) own one whole tile each (XCD-aware order:
     // block b runs on XCD b % 8, consecutive tiles share activation rows).  Blocks >= n_main are the
@@ -606,6 +673,7 @@ igemm_kernel(const IGemmArgs p) {
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
         tl_stamp(p.tl, 8);
+        if (!is_tail) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);   // oldest loads of the kernel
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
         tl_stamp(p.tl, 9);
@@ -815,16 +883,18 @@ igemm_kernel(const IGemmArgs p) {
         tl_end(p.tl);
         return;
     }
+    Par par;
+    par.lds = GLDS ? smem + PAR_OFF : nullptr; par.n0 = n0; par.b0 = HW > 0 ? m0 / HW : 0; par.bnp = par_bnp(BN);
     constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
     if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
-        igemm_epilogue_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)));
+        igemm_epilogue_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)), par);
         tl_end(p.tl);
         return;
     }
     if constexpr (NT % 2 == 0) {
         if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
-            igemm_epilogue_geglu_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)));
+            igemm_epilogue_geglu_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)), par);
             tl_end(p.tl);
             return;
         }
@@ -833,11 +903,11 @@ igemm_kernel(const IGemmArgs p) {
     constexpr bool HEADS_FITS = WM * WN * NT * 2560 <= NST * STAGE_BYTES && MT * NT <= 8;
     if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
         (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
-        igemm_epilogue_heads_staged<MT, NT>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560));
+        igemm_epilogue_heads_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560), par);
         tl_end(p.tl);
         return;
     }
-    igemm_epilogue<MT, NT>(p, acc, mw0, nw0, lane);
+    igemm_epilogue<MT, NT, GLDS>(p, acc, mw0, nw0, lane, par);
     tl_end(p.tl);
 }
 
@@ -874,7 +944,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += base[sidx * sstride + (long)r * NTHR];
     }
-    igemm_epilogue<1, 1>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane);
+    Par par; par.lds = nullptr; par.n0 = 0; par.b0 = 0; par.bnp = 0;      // parameters from global memory
+    igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par);
 }
 
 // ---- 128 x 160 tile as EIGHT waves of 32 x 80 on v_mfma_f32_16x16x32_f16 --------------------------------------------
@@ -894,8 +965,9 @@ igemm_reduce_kernel(const IGemmArgs p) {
 //     (cfgpp_igemm_set_mf16_heads); whole tiles only (no K-split).
 // The 16 x 16 x 32 MFMA sums k in a different order than the 32 x 32 x 16 one, so this tile is NOT a tuner candidate (the
 // tuner's choices must not change results): it is used by rule (igemm_launch; cfgpp_igemm_set_mf16) or forced (configs 18 / 19).
+template <bool L = true>
 __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
-                                                        char* stg /* wave-private, 32 * 176 bytes */) {
+                                                        char* stg /* wave-private, 32 * 176 bytes */, const Par& par) {
     constexpr int WTN = 80, PITCH = WTN * 2 + 16, CPR = WTN / 8, NQ = (32 * CPR + 63) / 64;
     const int c16 = lane & 15, fq = lane >> 4;
     const int HW = p.rows_per_batch;
@@ -909,23 +981,11 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
         if (p.omode == 1) opix = pp;
         if (p.rmode == 1) rpix = pp;
     }
-    // the residual pieces this lane will add are requested FIRST: their latency (HBM / Infinity Cache under load) runs
-    // under the bias / convert / LDS-transpose work below instead of after it
-    half8_t rres[NQ];
-    long ooff[NQ];
-    bool live[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int c = lane + 64 * q;
-        const int r = c / CPR, cc = c - r * CPR;
-        const int op = __shfl(opix, r), rp = __shfl(rpix, r);
-        const int mm = mw0 + r, n = nw0 + cc * 8;
-        live[q] = c < 32 * CPR && mm < p.M && n < p.N;
-        ooff[q] = (long)op * p.old + n;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rres[q][k] = (half_t)0.f;
-        if (live[q] && p.resid) rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
-    }
+    // Order matters.  (1) the parameter segments (bias + time embedding of this lane's columns and rows) are read from LDS FIRST:
+    // each of those reads carries a compiler-inserted vmcnt(0) (the segments were written by LDS-DMA), free while nothing else
+    // is in flight.  (2) the residual pieces are requested in ONE block of loads (clamped addresses, no per-piece branch).
+    // (3) scale / add / convert / transpose through LDS run under their latency.  (4) read back, add the residual, store.
+    float4 add[2][5];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = mw0 + i * 16 + c16;
@@ -933,38 +993,52 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
         const int b = (HW > 0) ? mc / HW : 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int nl = j * 16 + 4 * fq;
-            int n = nw0 + nl;
+            int n = nw0 + j * 16 + 4 * fq;
             n = n < p.N ? n : p.N - 4;
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k] * p.out_scale;
-            if (p.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
+            add[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) add[i][j] = par_bias4<L>(p, par, n);
             if (p.temb) {
-                const float4 tt = *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
-                v[0] += tt.x; v[1] += tt.y; v[2] += tt.z; v[3] += tt.w;
+                const float4 tt = par_temb4<L>(p, par, b, n);
+                add[i][j].x += tt.x; add[i][j].y += tt.y; add[i][j].z += tt.z; add[i][j].w += tt.w;
             }
-            half4_t o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (half_t)v[k];
-            *reinterpret_cast<half4_t*>(stg + (i * 16 + c16) * PITCH + nl * 2) = o;
         }
     }
+    half8_t rres[NQ];
+    if (p.resid) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = lane + 64 * q;
+            const int r = c / CPR, cc = c - r * CPR;
+            const int rp = __shfl(rpix, r);
+            int n = nw0 + cc * 8;
+            n = n < p.N ? n : p.N - 8;
+            rres[q] = *reinterpret_cast<const half8_t*>(p.resid + (long)rp * p.rld + n);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int nl = j * 16 + 4 * fq;
+            half4_t o;
+            o[0] = (half_t)(acc[i][j][0] * p.out_scale + add[i][j].x);
+            o[1] = (half_t)(acc[i][j][1] * p.out_scale + add[i][j].y);
+            o[2] = (half_t)(acc[i][j][2] * p.out_scale + add[i][j].z);
+            o[3] = (half_t)(acc[i][j][3] * p.out_scale + add[i][j].w);
+            *reinterpret_cast<half4_t*>(stg + (i * 16 + c16) * PITCH + nl * 2) = o;
+        }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int c = lane + 64 * q;
         const int r = c / CPR, cc = c - r * CPR;
-        if (live[q]) {
-            half8_t v = *reinterpret_cast<const half8_t*>(stg + r * PITCH + cc * 16);
-            if (p.resid) {
+        const int op = __shfl(opix, r);
+        const int mm = mw0 + r, n = nw0 + cc * 8;
+        half8_t v = *reinterpret_cast<const half8_t*>(stg + (r & 31) * PITCH + cc * 16);
+        if (p.resid) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
-            }
-            *reinterpret_cast<half8_t*>(p.out + ooff[q]) = v;
+            for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
         }
+        if (c < 32 * CPR && mm < p.M && n < p.N) *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
     }
 }
 
@@ -973,8 +1047,9 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
 // [head dim][key position] (80-byte pitch, positions in the attention kernel's permuted order unless vt_linear) for V
 // columns - and leaves as 16-byte pieces: 8 head dims of one token, or 8 key positions of one head dim.
 // Needs rows_per_batch % 32 == 0, part_width % 16 == 0, head_dim % 8 == 0 (checked by mf16_supports).
+template <bool L = true>
 __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
-                                                              char* stg /* wave-private, 5 * 1536 bytes */) {
+                                                              char* stg /* wave-private, 5 * 1536 bytes */, const Par& par) {
     constexpr int BLK = 1536, QK_PITCH = 48, VT_PITCH = 80;
     if (mw0 >= p.M) return;
     const int c16 = lane & 15, fq = lane >> 4;
@@ -995,9 +1070,9 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
-            ln_apply4(p, v, lnst[i], n);
+            ln_apply4<L>(p, par, v, lnst[i], n);
             if (p.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                const float4 bb = par_bias4<L>(p, par, n);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
             if (part == 2) {
@@ -1153,6 +1228,8 @@ igemm16_kernel(const IGemmArgs p) {
 
     const int nk = p.K >> 6;
     tl_stamp(p.tl, 8);
+    constexpr int PAR_OFF = NST * STAGE_BYTES;      // epilogue parameters behind the ring
+    par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1247,8 +1324,10 @@ igemm16_kernel(const IGemmArgs p) {
     tl_stamp(p.tl, 2);
 #undef CFGPP_WAIT_TILES
 
-    if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536));
-    else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176));
+    Par par;
+    par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? m0 / HW : 0; par.bnp = par_bnp(BN);
+    if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536), par);
+    else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176), par);
     tl_end(p.tl);
 }
 
@@ -1275,7 +1354,8 @@ extern "C" void cfgpp_igemm_set_n_major(int mode) { g_n_major = mode; }
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem = NST * (BM + BN) * 128;
+    constexpr int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) : 0);      // ring + epilogue-parameter segments
+    static_assert(smem <= 160 * 1024, "tile does not fit the LDS");
     constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     static bool attr_set = false;
@@ -1351,7 +1431,7 @@ static bool mf16_supports(const IGemmArgs& a) {
 }
 template <int AMODE, int NST>
 int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
-    constexpr int smem = NST * (128 + 160) * 128;
+    constexpr int smem = NST * (128 + 160) * 128 + par_bytes(160);
     static bool attr_set = false;
     auto kern = igemm16_kernel<AMODE, NST>;
     if (!attr_set) {
@@ -1476,6 +1556,8 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.amode != 3 || (a.H < 2048 && a.W < 2048 && (a.M / a.rows_per_batch) < 512), "igemm: upsample range");
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
+    CFGPP_REQUIRE(a.temb == nullptr || a.rows_per_batch * (PAR_NB - 1) >= 256,
+                  "igemm: a time-embedding epilogue needs H*W >= 64 (%d rows per batch): %d batches of a tile are staged", a.rows_per_batch, PAR_NB);
     CFGPP_REQUIRE(a.ln_stats == nullptr || (a.ln_c != nullptr && a.epi != EPI_STORE && a.amode == 0),
                   "igemm: the fused LayerNorm needs ln_c and a token-major EPI_HEADS / EPI_GEGLU launch");
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for

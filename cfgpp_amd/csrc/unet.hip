@@ -39,10 +39,13 @@ struct cfgpp_unet : EngineBase {
 
 };
 
-// 1 (default): the three LayerNorms of a transformer block are folded into the projections that consume them (QKV, cross-Q,
-// GEGLU): a statistics pass instead of a normalise-and-write pass, weights scaled by gamma, beta folded into the bias.
-// 0: separate layernorm launches writing the normalised rows (round-2 plan; A/B and fallback).  Read at finalize.
-static int g_fuse_ln = 1;
+// 1: the three LayerNorms of a transformer block are folded into the projections that consume them (QKV, cross-Q, GEGLU): a
+// statistics pass instead of a normalise-and-write pass, weights scaled by gamma, beta folded into the bias.
+// 0 (default): separate layernorm launches writing the normalised rows.  Read at finalize.
+// Measured in situ (profiles/r03/ab/ln_fusion.txt): the statistics pass is 35 % cheaper than the LayerNorm it replaces (SDXL
+// 4 rows: 2.36 -> 1.56 ms per forward), but both are latency-bound launches, and the consumers' epilogues paid the saving back
+// (+0.98 ms) - so it stays opt-in until the statistics come out of the PRODUCING GEMM's epilogue and the launches disappear.
+static int g_fuse_ln = 0;
 extern "C" void cfgpp_unet_set_fuse_ln(int on) { g_fuse_ln = on ? 1 : 0; }
 
 namespace {
