@@ -374,19 +374,19 @@ ln_stats_kernel(const half_t* __restrict__ x, float2* __restrict__ stats, long r
     if (row >= rows) return;
     const int chunks = C / 8;
     const half_t* xr = x + row * C;
+    half8_t raw[MAXV];                              // every load first (clamped chunk index), then the arithmetic
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int ch = lane + j * 64;
+        raw[j] = *reinterpret_cast<const half8_t*>(xr + (ch < chunks ? ch : chunks - 1) * 8);
+    }
     float v[MAXV][8];
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int ch = lane + j * 64;
-        if (ch < chunks) {
-            const half8_t h = *reinterpret_cast<const half8_t*>(xr + ch * 8);
+        const bool live = lane + j * 64 < chunks;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { v[j][k] = (float)h[k]; sum += v[j][k]; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[j][k] = 0.f;
-        }
+        for (int k = 0; k < 8; ++k) { v[j][k] = live ? (float)raw[j][k] : 0.f; sum += v[j][k]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -394,43 +394,47 @@ ln_stats_kernel(const half_t* __restrict__ x, float2* __restrict__ stats, long r
     float sq = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int ch = lane + j * 64;
-        if (ch < chunks) {
+        const bool live = lane + j * 64 < chunks;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += d * d; }
-        }
+        for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += live ? d * d : 0.f; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if (lane == 0) stats[row] = make_float2(mean, rsqrtf(sq / (float)C + eps));
 }
 
-template <int MAXV, int RPW>   // MAXV = max half4 chunks per lane (C <= 64*4*MAXV)
+template <int MAXV, int RPW>   // MAXV = max 16-byte chunks (8 channels) per lane: C <= 64 * 8 * MAXV
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
                  const float* __restrict__ beta, long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     if (row0 >= rows) return;
-    const int chunks = C / 4;
-    float v[RPW][MAXV][4];
-    float sum[RPW];
+    const int chunks = C / 8;
+    // ALL loads of the wave's rows are issued before anything waits for one of them: unconditional, with the chunk index
+    // clamped (round 2's `if (ch < chunks) { load; use }` put every load in its own block with its own s_waitcnt vmcnt(0): a row
+    // of C = 1280 was five dependent memory round trips, and the kernel was latency-bound at 2 TB/s)
+    half8_t raw[RPW][MAXV];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const long row = row0 + r < rows ? row0 + r : rows - 1;      // clamp: the tail rows are computed twice, stored once
         const half_t* xr = x + row * C;
-        sum[r] = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
             const int ch = lane + j * 64;
-            if (ch < chunks) {
-                const half4_t h = *reinterpret_cast<const half4_t*>(xr + ch * 4);
+            raw[r][j] = *reinterpret_cast<const half8_t*>(xr + (ch < chunks ? ch : chunks - 1) * 8);
+        }
+    }
+    float v[RPW][MAXV][8];
+    float sum[RPW];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { v[r][j][k] = (float)h[k]; sum[r] += v[r][j][k]; }
-            } else {
+    for (int r = 0; r < RPW; ++r) {
+        sum[r] = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[r][j][k] = 0.f;
-            }
+        for (int j = 0; j < MAXV; ++j) {
+            const bool live = lane + j * 64 < chunks;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[r][j][k] = live ? (float)raw[r][j][k] : 0.f; sum[r] += v[r][j][k]; }
         }
     }
     float mean[RPW], rstd[RPW];
@@ -442,31 +446,36 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const flo
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
-            const int ch = lane + j * 64;
-            if (ch < chunks) {
+            const bool live = lane + j * 64 < chunks;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const float d = v[r][j][k] - mean[r]; sq += d * d; }
-            }
+            for (int k = 0; k < 8; ++k) { const float d = v[r][j][k] - mean[r]; sq += live ? d * d : 0.f; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
         rstd[r] = rsqrtf(sq / (float)C + eps);
     }
+    // gamma / beta of this lane's chunks: again every load first
+    float4 g[MAXV][2], be[MAXV][2];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int ch = lane + j * 64;
+        const int cc = (ch < chunks ? ch : chunks - 1) * 8;
+        g[j][0] = *reinterpret_cast<const float4*>(gamma + cc); g[j][1] = *reinterpret_cast<const float4*>(gamma + cc + 4);
+        be[j][0] = *reinterpret_cast<const float4*>(beta + cc); be[j][1] = *reinterpret_cast<const float4*>(beta + cc + 4);
+    }
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         const int ch = lane + j * 64;
         if (ch < chunks) {
-            const float4 g = *reinterpret_cast<const float4*>(gamma + ch * 4);
-            const float4 b = *reinterpret_cast<const float4*>(beta + ch * 4);
+            const float gg[8] = {g[j][0].x, g[j][0].y, g[j][0].z, g[j][0].w, g[j][1].x, g[j][1].y, g[j][1].z, g[j][1].w};
+            const float bb[8] = {be[j][0].x, be[j][0].y, be[j][0].z, be[j][0].w, be[j][1].x, be[j][1].y, be[j][1].z, be[j][1].w};
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 if (row0 + r < rows) {
-                    half4_t o;
-                    o[0] = (half_t)((v[r][j][0] - mean[r]) * rstd[r] * g.x + b.x);
-                    o[1] = (half_t)((v[r][j][1] - mean[r]) * rstd[r] * g.y + b.y);
-                    o[2] = (half_t)((v[r][j][2] - mean[r]) * rstd[r] * g.z + b.z);
-                    o[3] = (half_t)((v[r][j][3] - mean[r]) * rstd[r] * g.w + b.w);
-                    *reinterpret_cast<half4_t*>(y + (row0 + r) * C + ch * 4) = o;
+                    half8_t o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[k] = (half_t)((v[r][j][k] - mean[r]) * rstd[r] * gg[k] + bb[k]);
+                    *reinterpret_cast<half8_t*>(y + (row0 + r) * C + ch * 8) = o;
                 }
             }
         }
@@ -629,19 +638,19 @@ int cfgpp_op_ln_stats(const void* x, float* stats, long rows, int C, float eps, 
 
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream) {
-    CFGPP_REQUIRE(C % 4 == 0 && C <= 64 * 4 * 8, "layernorm: C=%d must be a multiple of 4 and <= 2048", C);
+    CFGPP_REQUIRE(C % 8 == 0 && C <= 64 * 8 * 4, "layernorm: C=%d must be a multiple of 8 and <= 2048", C);
     CFGPP_REQUIRE(x && y && gamma && beta && rows > 0, "layernorm: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const int need = cdiv(C / 4, 64);
+    const int need = cdiv(C / 8, 64);
     // rows per wave: 2 for the 640-byte rows of the C = 320 level when there are enough rows to keep the CUs full
-    // (measured 25.3 -> 22.4 us at 65536 rows; flat or worse for longer rows and at 4 rows per wave)
     const int rpw = g_ln_rpw > 0 ? g_ln_rpw : (C <= 320 && rows >= 2L * 4096 ? 2 : 1);
 #define LN_LAUNCH(MV, RP) hipLaunchKernelGGL((layernorm_kernel<MV, RP>), dim3(cdiv(rows, 4 * RP)), dim3(256), 0, s, \
                                              (const half_t*)x, (half_t*)y, gamma, beta, rows, C, eps)
 #define LN_BY_RPW(MV) do { if (rpw >= 4) LN_LAUNCH(MV, 4); else if (rpw == 2) LN_LAUNCH(MV, 2); else LN_LAUNCH(MV, 1); } while (0)
-    if (need <= 2) LN_BY_RPW(2);
-    else if (need <= 5) LN_BY_RPW(5);
-    else LN_BY_RPW(8);
+    if (need <= 1) LN_BY_RPW(1);
+    else if (need <= 2) LN_BY_RPW(2);
+    else if (need <= 3) LN_BY_RPW(3);
+    else LN_LAUNCH(4, 1);
 #undef LN_BY_RPW
 #undef LN_LAUNCH
     CFGPP_HIP_CHECK(hipGetLastError());
