@@ -74,9 +74,10 @@ __device__ __forceinline__ float2 ln_row(const IGemmArgs& p, int m) {
 // not for bandwidth.  Now the tile's BN-column segments of those vectors go HBM -> LDS by LDS-DMA (4 bytes per lane) as the
 // FIRST loads of the kernel: they are older than every K-tile piece, so the counted vmcnt of the K loop covers them, the
 // K loop's barriers publish them, and the epilogue reads them with ds_read_b128.
-constexpr int PAR_NB = 5;                                  // time-embedding rows (batches) staged per tile: BM <= 256, H*W >= 64
+constexpr int PAR_NB = 5;                                  // time-embedding rows (batches) of a tile when H*W >= 64 (BM <= 256): the sizes the
+                                                           // occupancy figures assume; smaller feature maps take IGemmArgs::par_nb rows
 __host__ __device__ constexpr int par_bnp(int BN) { return (BN + 63) / 64 * 64; }
-__host__ __device__ constexpr int par_bytes(int BN) { return par_bnp(BN) * 4 * (2 + PAR_NB); }
+__host__ __device__ constexpr int par_bytes(int BN, int nb = PAR_NB) { return par_bnp(BN) * 4 * (2 + nb); }
 struct Par {
     const char* lds;     // null: read the parameters from global memory (register-staged kernels, the K-split reduce kernel)
     int n0, b0, bnp;     // first column / first batch of the tile, padded segment length (floats)
@@ -104,8 +105,7 @@ __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0,
     if (p.bias) arr(p.bias, 0);
     if (p.ln_stats) arr(p.ln_c, 1);
     if (p.temb) {
-#pragma unroll
-        for (int k = 0; k < PAR_NB; ++k) {
+        for (int k = 0; k < p.par_nb; ++k) {               // (run-time count: 2 .. 5 for H*W >= 64)
             int b = b0 + k;
             b = b < nb ? b : nb - 1;
             arr(p.temb + (long)b * p.temb_ld, 2 + k);
@@ -126,8 +126,8 @@ __device__ __forceinline__ float4 par_lnc4(const IGemmArgs& p, const Par& q, int
 template <bool L>
 __device__ __forceinline__ float4 par_temb4(const IGemmArgs& p, const Par& q, int b, int n) {
     if constexpr (L) {
-        int k = b - q.b0;                              // < PAR_NB: igemm_launch requires H*W >= 64 for launches with a time embedding
-        k = k < PAR_NB ? k : PAR_NB - 1;
+        int k = b - q.b0;                              // < par_nb by the launcher's choice of par_nb
+        k = k < p.par_nb ? k : p.par_nb - 1;
         return *reinterpret_cast<const float4*>(q.lds + ((2 + k) * q.bnp + n - q.n0) * 4);
     } else {
         return *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
@@ -673,9 +673,13 @@ igemm_kernel(const IGemmArgs p) {
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
         tl_stamp(p.tl, 8);
-        if (!is_tail) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);   // oldest loads of the kernel
+        // par_late = 0: the parameter segments are the oldest loads of the kernel (covered by every counted wait).  1: they follow
+        // the prologue's tiles - the counted waits then hold back up to that many tile pieces more in the first NST-1 tiles
+        // (conservative, still correct) and the loop's draining waits + barriers publish the segments before the epilogue.
+        if (!is_tail && !p.par_late) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
+        if (!is_tail && p.par_late) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
         tl_stamp(p.tl, 9);
         if (NST > 2 && nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");   // NST-1 tiles issued: the oldest has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1229,7 +1233,7 @@ igemm16_kernel(const IGemmArgs p) {
     const int nk = p.K >> 6;
     tl_stamp(p.tl, 8);
     constexpr int PAR_OFF = NST * STAGE_BYTES;      // epilogue parameters behind the ring
-    par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
+    if (!p.par_late) par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1238,6 +1242,7 @@ igemm16_kernel(const IGemmArgs p) {
             for (int q = 0; q < 4; ++q) piece(q, s_, s_, g);
             if (b3) piece(4, s_, s_, g);
         }
+    if (p.par_late) par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);           // (see igemm_kernel: conservative counted waits)
     tl_stamp(p.tl, 9);
     if (nk >= NST - 1) CFGPP_WAIT_TILES(NST - 2);      // NST-1 tiles issued: the oldest has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1351,21 +1356,37 @@ static int g_tail_split = 1;                        // 1 = K-split tiny grids wi
 static int g_n_major = -1;                          // tile walk: -1 = by operand bytes, 0 = always M-major, 1 = always N-major
 extern "C" void cfgpp_igemm_set_n_major(int mode) { g_n_major = mode; }
 
+// time-embedding rows a BM-row tile stages: every batch its rows can touch (a tile starts anywhere inside a batch)
+static int par_slots(const IGemmArgs& a, int BM) {
+    if (a.temb == nullptr || a.rows_per_batch <= 0) return 0;
+    const int HW = a.rows_per_batch, nbatch = cdiv(a.M, HW);
+    const int span = (BM + HW - 1) / HW + 1;
+    return span < nbatch ? span : nbatch;
+}
+
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) : 0);      // ring + epilogue-parameter segments
-    static_assert(smem <= 160 * 1024, "tile does not fit the LDS");
-    constexpr int blocks_per_cu = (160 * 1024) / smem < 8 ? (160 * 1024) / smem : 8;
+    constexpr int smem_std = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) : 0);      // ring + epilogue-parameter segments
+    static_assert(smem_std <= 160 * 1024, "tile does not fit the LDS");
+    constexpr int blocks_per_cu = (160 * 1024) / smem_std < 8 ? (160 * 1024) / smem_std : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
-    static bool attr_set = false;
+    IGemmArgs a = a_in;
+    a.par_nb = par_slots(a, BM);
+    const int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) : 0);
+    if (smem > 160 * 1024) {
+        // feature maps under 8 x 8 with a time embedding (images under 64 px per side at the bottom level): a big tile spans more
+        // batches than its LDS can stage rows for - the 64 x 64 tile (<= 66 rows of 64 floats) always fits
+        if constexpr (WM * WTM > 64 || WN * WTN > 64 || NST != 2) return launch_cfg_amode<2, 2, 32, 32, GLDS, AMODE, 2>(a_in, stream);
+        else { cfgpp_set_error("igemm: %d time-embedding rows per tile do not fit the LDS", a.par_nb); return -2; }
+    }
+    static int attr_smem = 0;
     auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
-    if (!attr_set) {
+    if (smem > attr_smem) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_smem = smem;
     }
-    IGemmArgs a = a_in;
     const int T = cdiv(a.M, BM) * cdiv(a.N, BN);
     const int KT = a.K >> 6;
     a.n_main = T; a.ksplit = 1; a.ws = nullptr; a.staged_epi = g_staged_epi;
@@ -1431,14 +1452,16 @@ static bool mf16_supports(const IGemmArgs& a) {
 }
 template <int AMODE, int NST>
 int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
-    constexpr int smem = NST * (128 + 160) * 128 + par_bytes(160);
-    static bool attr_set = false;
-    auto kern = igemm16_kernel<AMODE, NST>;
-    if (!attr_set) {
-        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
     IGemmArgs a = a_in;
+    a.par_nb = par_slots(a, 128);
+    const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB);
+    if (smem > 160 * 1024) return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2>(a_in, stream);   // (feature maps under 8 x 8: see launch_cfg_amode)
+    static int attr_smem = 0;
+    auto kern = igemm16_kernel<AMODE, NST>;
+    if (smem > attr_smem) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_smem = smem;
+    }
     const int ntm = cdiv(a.M, 128), ntn = a.N / 160;
     a.n_main = ntm * ntn; a.ksplit = 1; a.ws = nullptr; a.staged_epi = 1;
     const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
@@ -1461,6 +1484,8 @@ int launch_mf16(const IGemmArgs& a, hipStream_t stream) {
     }
 }
 
+static int g_par_late = 0;             // 1: the epilogue-parameter DMAs follow the prologue's tile DMAs instead of preceding them
+extern "C" void cfgpp_igemm_set_par_late(int on) { g_par_late = on ? 1 : 0; }
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
@@ -1545,6 +1570,7 @@ extern "C" void cfgpp_igemm_timeline_info(int* out12) { for (int i = 0; i < 12; 
 int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.allow_split = 1;
+    a.par_late = g_par_late;
     a.tl = nullptr;
     if (g_tl) { if (g_tl_count == g_tl_target) a.tl = g_tl; ++g_tl_count; }
     const int Cin = a.C0 + a.C1;
@@ -1556,8 +1582,6 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.amode != 3 || (a.H < 2048 && a.W < 2048 && (a.M / a.rows_per_batch) < 512), "igemm: upsample range");
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
-    CFGPP_REQUIRE(a.temb == nullptr || a.rows_per_batch * (PAR_NB - 1) >= 256,
-                  "igemm: a time-embedding epilogue needs H*W >= 64 (%d rows per batch): %d batches of a tile are staged", a.rows_per_batch, PAR_NB);
     CFGPP_REQUIRE(a.ln_stats == nullptr || (a.ln_c != nullptr && a.epi != EPI_STORE && a.amode == 0),
                   "igemm: the fused LayerNorm needs ln_c and a token-major EPI_HEADS / EPI_GEGLU launch");
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for

@@ -19,6 +19,7 @@ name, rows = sys.argv[1], int(sys.argv[2])
 wanted = sys.argv[3:]
 lib = _lib.load()
 lib.cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))
+lib.cfgpp_igemm_set_par_late(int(os.environ.get("PAR_LATE", "0")))
 lib.cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))
 eng = HipEngine(name, max_batch=rows // 2)
 cfg, B = eng.cfg, rows // 2

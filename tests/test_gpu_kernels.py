@@ -55,6 +55,12 @@ def test_conv3x3_bias_temb_residual(diag):
     assert all(v["halo_zero"] for v in r.values())
 
 
+def test_conv3x3_time_embedding_on_small_feature_maps(diag):
+    """H*W < 64: more batches per tile than the standard 5 staged rows (4x4 and 2x2 maps, ragged batch counts)"""
+    r = _check(diag, diag.t_conv_temb_small, "conv3x3_temb_small_maps")
+    assert all(v["halo_zero"] for v in r.values())
+
+
 def test_conv3x3_stride2(diag):
     _check(diag, diag.t_conv_s2, "conv3x3_stride2")
 
