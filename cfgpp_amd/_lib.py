@@ -104,7 +104,6 @@ PROTOTYPES = {
     "cfgpp_igemm_set_split_tile": (None, [_I]),
     "cfgpp_igemm_set_mf16": (None, [_I]),
     "cfgpp_igemm_set_mf16_rounds": (None, [_I]),
-    "cfgpp_igemm_set_par_late": (None, [_I]),
     "cfgpp_igemm_set_mf16_heads": (None, [_I]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
@@ -146,7 +145,7 @@ def load():
     if os.environ.get("CFGPP_AUTOTUNE", "1") == "0":      # e.g. under rocprofv3 --pmc: no timing passes
         lib.cfgpp_igemm_set_autotune(0)
     # A/B knobs of opt-in kernel variants (measurement runs; the defaults are what the library ships)
-    for env, fn in (("CFGPP_FUSE_LN", lib.cfgpp_unet_set_fuse_ln), ("CFGPP_PAR_LATE", lib.cfgpp_igemm_set_par_late)):
+    for env, fn in (("CFGPP_FUSE_LN", lib.cfgpp_unet_set_fuse_ln),):
         if os.environ.get(env, "") != "":
             fn(int(os.environ[env]))
     _lib = lib

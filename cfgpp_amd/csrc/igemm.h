@@ -60,7 +60,6 @@ struct IGemmArgs {
     const float* ln_stats;    // [M][2] = (mean, rstd) per row (cfgpp_op_ln_stats), or null: no LayerNorm
     const float* ln_c;        // [N] = sum_k W'[n][k] (packed order for GEGLU)
     // ---- diagnostics (cfgpp_igemm_timeline): per-workgroup time stamps of ONE chosen launch, null otherwise ----
-    int par_late;             // 1: stage the epilogue parameters after the prologue's tiles (A/B knob)
     int par_nb;               // time-embedding rows (batches) a tile stages in LDS (set by the launcher: covers every batch a tile's rows touch)
     unsigned long long* tl;   // [grid][16]: s_memtime at {entry, first tile landed, k-loop done, stores done}, s_memrealtime at
                               // {entry, exit}, HW_ID | XCC_ID << 32, s_memtime after the first K-tile, s_memtime {before the

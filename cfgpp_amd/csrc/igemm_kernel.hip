@@ -53,9 +53,25 @@ __device__ __forceinline__ void tl_end(unsigned long long* tl) {
     }
 }
 
+// floor(m / d), m >= 0, for SMALL quotients (batch indices, image rows: < 2^20): one multiply by the hardware reciprocal and a
+// one-step correction instead of the ~35-instruction integer-division sequence (no integer divider on the VALU).  The
+// approximation is off by less than 0.4 for quotients below 2^20 even with a 2-ulp reciprocal, so one correction is exact
+// (swept on the CPU over boundary cases for every divisor class the engines use).
+__device__ __forceinline__ int qdiv(int m, int d) {
+    // (the divisor is made opaque HERE: left alone, the compiler hoists the reciprocals of H*W and W to the top of the kernel and
+    //  keeps them in VGPRs across the K loop, which pushed the 256-VGPR 256 x 320 kernel into 100 spills)
+    int dv = d;
+    asm volatile("" : "+v"(dv));
+    const float inv = __builtin_amdgcn_rcpf((float)dv);
+    int q = (int)((float)m * inv);
+    const int r = m - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
+}
+
 __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
-    const int b = m / HW, p = m - b * HW;
-    const int y = p / W, x = p - y * W;
+    const int b = qdiv(m, HW), p = m - b * HW;
+    const int y = qdiv(p, W), x = p - y * W;
     return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
 }
 
@@ -88,7 +104,7 @@ __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0,
     constexpr int BNP = par_bnp(BN), NPC = BNP / 64;
     int nn = n0 + lane;                                     // + 64 * piece, clamped per piece
     const int HW = p.rows_per_batch;
-    const int b0 = HW > 0 ? m0 / HW : 0;
+    const int b0 = HW > 0 ? qdiv(m0, HW) : 0;
     const int nb = HW > 0 ? (p.M + HW - 1) / HW : 1;
     int pi = 0;                                             // running piece index -> wave pi % NW (compile-time after unrolling)
     auto arr = [&](const float* src, int slot) {
@@ -152,7 +168,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     for (int i = 0; i < MT; ++i) {
         const int m = mw0 + i * 32 + frow;
         if (m >= p.M) continue;
-        const int b = (HW > 0) ? m / HW : 0;
+        const int b = (HW > 0) ? qdiv(m, HW) : 0;
         const int tok = m - b * HW;
         const float2 lnst = ln_row(p, m);
         long orow = m, rrow = m;
@@ -280,7 +296,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
     for (int i = 0; i < MT; ++i) {
         const int m = mw0 + i * 32 + frow;
         const int mc = m < p.M ? m : p.M - 1;
-        const int b = (HW > 0) ? mc / HW : 0;
+        const int b = (HW > 0) ? qdiv(mc, HW) : 0;
         // this lane's row: output / residual pixel index (shared with the other lanes by shuffle below)
         int opix = mc, rpix = mc;
         if (p.omode == 1 || p.rmode == 1) {
@@ -389,6 +405,29 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
     }
 }
 
+// Head-major addressing without per-piece integer divisions.  A runtime-divisor division is a ~35-instruction VALU sequence;
+// the staged heads epilogues did two per 16-byte piece plus one per group in each loop (52 per wave on the 256 x 256 tile:
+// ~15 000 of the ~34 000 epilogue cycles the round-3 timeline shows for the QKV projections).  The first column of an
+// aligned column group is wave-uniform, so (part, head, offset in the head) are computed ONCE per group and a piece
+// `off` columns further (off < 32 <= head_dim) is at most one conditional wrap away.
+struct HeadCol { int part, head, dd; };
+__device__ __forceinline__ HeadCol head_col(const IGemmArgs& p, int ng_uniform) {
+    const int ng = __builtin_amdgcn_readfirstlane(ng_uniform);
+    const int pr = ng / p.part_width, cn0 = ng - pr * p.part_width;
+    const int h = cn0 / p.head_dim;
+    HeadCol c; c.part = pr + p.part0; c.head = h; c.dd = cn0 - h * p.head_dim;
+    return c;
+}
+__device__ __forceinline__ void head_step(const IGemmArgs& p, const HeadCol& c, int off, int& head, int& dd) {
+    dd = c.dd + off; head = c.head;
+    if (p.head_dim >= 32) {
+        if (dd >= p.head_dim) { dd -= p.head_dim; ++head; }
+    } else {                                                   // (head dims under 32: test-sized models only)
+        const int q = dd / p.head_dim;
+        head += q; dd -= q * p.head_dim;
+    }
+}
+
 // EPI_HEADS through LDS.  The plain epilogue above scatters 8-byte pieces (Q, K) and - for V^T, which is stored
 // transposed - single halves (4 two-byte stores per lane and accumulator group): measured, the QKV projection ran at
 // 664 TF/s where the same GEMM with a plain store runs at 930.  Here every 32-token x 32-column accumulator sub-tile is
@@ -404,16 +443,19 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
     const int ppos = cfgpp_vt_pos(frow);                       // this lane's token -> key position inside its 32-block
+    HeadCol hc[NT];                                            // per 32-column group: part / head / offset of its first column
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { const int ng = nw0 + j * 32; hc[j] = head_col(p, ng < p.N ? ng : p.N - 32); }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int m0s = mw0 + i * 32;                          // first token row of the sub-tile (multiple of 32)
+        const int m0s = __builtin_amdgcn_readfirstlane(mw0 + i * 32);   // first token row of the sub-tile (multiple of 32)
         if (m0s >= p.M) continue;
-        const int b = m0s / HW, tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
+        const int b = qdiv(m0s, HW), tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
         const float2 lnst = ln_row(p, m0s + frow);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ng = nw0 + j * 32;                       // first column of the 32-column group
-            const int part = (ng < p.N ? ng : p.N - 32) / p.part_width + p.part0;
+            const int part = hc[j].part;
             char* blk = stg + j * BLK;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -446,7 +488,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
         for (int j = 0; j < NT; ++j) {
             const int ng = nw0 + j * 32;
             if (ng >= p.N) continue;
-            const int part = ng / p.part_width + p.part0;
+            const int part = hc[j].part;
             const char* blk = stg + j * BLK;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -454,15 +496,15 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
                 const int r = c >> 2, c4 = c & 3;
                 const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * PITCH + c4 * 16);
                 if (part == 2) {                               // row r = head-dim column ng + r, piece = 8 key positions
-                    const int cn = (ng + r) % p.part_width;
-                    const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+                    int head, dd;
+                    head_step(p, hc[j], r, head, dd);
                     const long bh = (long)b * p.heads + head;
                     if (ng + r < p.N)
                         *reinterpret_cast<half8_t*>(p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok0 + 8 * c4) = v;
                 } else {                                       // row r = token tok0 + r, piece = 8 head dims
                     const int n = ng + 8 * c4;
-                    const int cn = n % p.part_width;
-                    const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+                    int head, dd;
+                    head_step(p, hc[j], 8 * c4, head, dd);
                     const long bh = (long)b * p.heads + head;
                     half_t* base = part == 0 ? p.hq : p.hk;
                     const int tp = part == 0 ? p.q_tok_pad : p.tok_pad;
@@ -523,7 +565,7 @@ igemm_kernel(const IGemmArgs p) {
     // launches (GEGLU at M = 4096: 26 MB of weights vs 10 MB of activations; PMC showed 56 % L2 misses M-major).
     // The launcher picks by operand bytes (IGemmArgs::n_major); the result does not depend on it.
     // (one division by a launcher-provided divisor: a two-sided branch here cost the 256 x 320 kernel 30 VGPRs -> spills)
-    const int wq = wg / p.walk_div, wr = wg - wq * p.walk_div;          // walk_div = ntn (M-major) or ntm (N-major)
+    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;          // walk_div = ntn (M-major) or ntm (N-major)
     const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -542,10 +584,10 @@ igemm_kernel(const IGemmArgs p) {
         if constexpr (AMODE == 0) a_pix[j] = m;
         else if constexpr (AMODE == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
         else if constexpr (AMODE == 2) {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            const int b = qdiv(m, HW), q = m - b * HW, y = qdiv(q, p.W), x = q - y * p.W;
             a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1 + p.ashift) * (2 * p.W + 2) + 2 * x + 1 + p.ashift;
         } else {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            const int b = qdiv(m, HW), q = m - b * HW, y = qdiv(q, p.W), x = q - y * p.W;
             a_pix[j] = (b << 22) | (y << 11) | x;      // unpacked per tap
         }
     }
@@ -673,13 +715,12 @@ igemm_kernel(const IGemmArgs p) {
         // order of one tile time, so NST = 2 stalls at the end-of-tile wait).
         const int nk = kt_end - kt_begin;
         tl_stamp(p.tl, 8);
-        // par_late = 0: the parameter segments are the oldest loads of the kernel (covered by every counted wait).  1: they follow
-        // the prologue's tiles - the counted waits then hold back up to that many tile pieces more in the first NST-1 tiles
-        // (conservative, still correct) and the loop's draining waits + barriers publish the segments before the epilogue.
-        if (!is_tail && !p.par_late) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
+        // the parameter segments are the oldest loads of the kernel: covered by every counted wait.  (Requesting them AFTER the
+        // prologue's tiles instead - conservative counted waits, published by the loop's draining waits - measured the same
+        // in situ, profiles/r03/ab/par_late_ln_fusion_call6.txt, and the second copy of par_stage cost the 256 x 320 kernel 100 spills.)
+        if (!is_tail) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
-        if (!is_tail && p.par_late) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
         tl_stamp(p.tl, 9);
         if (NST > 2 && nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST > 2 ? (NST - 2) * NP : 0)) : "memory");   // NST-1 tiles issued: the oldest has landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -888,7 +929,7 @@ igemm_kernel(const IGemmArgs p) {
         return;
     }
     Par par;
-    par.lds = GLDS ? smem + PAR_OFF : nullptr; par.n0 = n0; par.b0 = HW > 0 ? m0 / HW : 0; par.bnp = par_bnp(BN);
+    par.lds = GLDS ? smem + PAR_OFF : nullptr; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
     constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
     if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
@@ -994,7 +1035,7 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
     for (int i = 0; i < 2; ++i) {
         const int m = mw0 + i * 16 + c16;
         const int mc = m < p.M ? m : p.M - 1;
-        const int b = (HW > 0) ? mc / HW : 0;
+        const int b = (HW > 0) ? qdiv(mc, HW) : 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             int n = nw0 + j * 16 + 4 * fq;
@@ -1058,14 +1099,18 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     if (mw0 >= p.M) return;
     const int c16 = lane & 15, fq = lane >> 4;
     const int HW = p.rows_per_batch;
-    const int b = mw0 / HW, tok0 = mw0 - b * HW;               // one batch, one aligned 32-token block
+    const int mw0u = __builtin_amdgcn_readfirstlane(mw0);
+    const int b = qdiv(mw0u, HW), tok0 = mw0u - b * HW;            // one batch, one aligned 32-token block
+    HeadCol hc[5];                                             // per 16-column group: part / head / offset of its first column
+#pragma unroll
+    for (int j = 0; j < 5; ++j) hc[j] = head_col(p, nw0 + j * 16);
     float2 lnst[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) lnst[i] = ln_row(p, mw0 + i * 16 + c16);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ng = nw0 + j * 16;                           // first column of the 16-column group (ng < N: N % 160 == 0)
-        const int part = ng / p.part_width + p.part0;
+        const int part = hc[j].part;
         char* blk = stg + j * BLK;
         const int n = ng + 4 * fq;
 #pragma unroll
@@ -1094,21 +1139,20 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     // 64 pieces of 16 bytes per group: one per lane
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const int ng = nw0 + j * 16;
-        const int part = ng / p.part_width + p.part0;
+        const int part = hc[j].part;
         const char* blk = stg + j * BLK;
         if (part == 2) {                                       // row = head-dim column ng + r, piece = 8 key positions
             const int r = lane >> 2, c4 = lane & 3;
             const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * VT_PITCH + c4 * 16);
-            const int cn = (ng + r) % p.part_width;
-            const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+            int head, dd;
+            head_step(p, hc[j], r, head, dd);
             const long bh = (long)b * p.heads + head;
             *reinterpret_cast<half8_t*>(p.hvt + (bh * p.head_dim_pad + dd) * p.tok_pad + tok0 + 8 * c4) = v;
         } else {                                               // row = token tok0 + r, piece = 8 head dims
             const int r = lane >> 1, c2 = lane & 1;
             const half8_t v = *reinterpret_cast<const half8_t*>(blk + r * QK_PITCH + c2 * 16);
-            const int cn = (ng + 8 * c2) % p.part_width;
-            const int head = cn / p.head_dim, dd = cn - head * p.head_dim;
+            int head, dd;
+            head_step(p, hc[j], 8 * c2, head, dd);
             const long bh = (long)b * p.heads + head;
             half_t* base = part == 0 ? p.hq : p.hk;
             const int tp = part == 0 ? p.q_tok_pad : p.tok_pad;
@@ -1136,7 +1180,7 @@ igemm16_kernel(const IGemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int wq = wg / p.walk_div, wr = wg - wq * p.walk_div;
+    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
     const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -1156,10 +1200,10 @@ igemm16_kernel(const IGemmArgs p) {
         if constexpr (AMODE == 0) a_pix[j] = m;
         else if constexpr (AMODE == 1) a_pix[j] = padded_pix(m, HW, p.W, p.H);
         else if constexpr (AMODE == 2) {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            const int b = qdiv(m, HW), q = m - b * HW, y = qdiv(q, p.W), x = q - y * p.W;
             a_pix[j] = (b * (2 * p.H + 2) + 2 * y + 1 + p.ashift) * (2 * p.W + 2) + 2 * x + 1 + p.ashift;
         } else {
-            const int b = m / HW, q = m - b * HW, y = q / p.W, x = q - y * p.W;
+            const int b = qdiv(m, HW), q = m - b * HW, y = qdiv(q, p.W), x = q - y * p.W;
             a_pix[j] = (b << 22) | (y << 11) | x;
         }
     }
@@ -1233,7 +1277,7 @@ igemm16_kernel(const IGemmArgs p) {
     const int nk = p.K >> 6;
     tl_stamp(p.tl, 8);
     constexpr int PAR_OFF = NST * STAGE_BYTES;      // epilogue parameters behind the ring
-    if (!p.par_late) par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
+    par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1242,7 +1286,6 @@ igemm16_kernel(const IGemmArgs p) {
             for (int q = 0; q < 4; ++q) piece(q, s_, s_, g);
             if (b3) piece(4, s_, s_, g);
         }
-    if (p.par_late) par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);           // (see igemm_kernel: conservative counted waits)
     tl_stamp(p.tl, 9);
     if (nk >= NST - 1) CFGPP_WAIT_TILES(NST - 2);      // NST-1 tiles issued: the oldest has landed
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1330,7 +1373,7 @@ igemm16_kernel(const IGemmArgs p) {
 #undef CFGPP_WAIT_TILES
 
     Par par;
-    par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? m0 / HW : 0; par.bnp = par_bnp(BN);
+    par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
     if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536), par);
     else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176), par);
     tl_end(p.tl);
@@ -1484,8 +1527,6 @@ int launch_mf16(const IGemmArgs& a, hipStream_t stream) {
     }
 }
 
-static int g_par_late = 0;             // 1: the epilogue-parameter DMAs follow the prologue's tile DMAs instead of preceding them
-extern "C" void cfgpp_igemm_set_par_late(int on) { g_par_late = on ? 1 : 0; }
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
@@ -1570,7 +1611,6 @@ extern "C" void cfgpp_igemm_timeline_info(int* out12) { for (int i = 0; i < 12; 
 int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.allow_split = 1;
-    a.par_late = g_par_late;
     a.tl = nullptr;
     if (g_tl) { if (g_tl_count == g_tl_target) a.tl = g_tl; ++g_tl_count; }
     const int Cin = a.C0 + a.C1;
@@ -1582,6 +1622,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.amode != 3 || (a.H < 2048 && a.W < 2048 && (a.M / a.rows_per_batch) < 512), "igemm: upsample range");
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
+    CFGPP_REQUIRE(a.rows_per_batch <= 0 || a.M / a.rows_per_batch < (1 << 20), "igemm: %d rows in batches of %d (batch index must stay below 2^20)", a.M, a.rows_per_batch);
     CFGPP_REQUIRE(a.ln_stats == nullptr || (a.ln_c != nullptr && a.epi != EPI_STORE && a.amode == 0),
                   "igemm: the fused LayerNorm needs ln_c and a token-major EPI_HEADS / EPI_GEGLU launch");
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for

@@ -279,8 +279,6 @@ void cfgpp_igemm_set_mf16(int mode);
 void cfgpp_igemm_set_mf16_heads(int on);
 /* A/B knob of that rule: also take grids of exactly 2 .. n full rounds of 256 tiles (default 1 = one round only) */
 void cfgpp_igemm_set_mf16_rounds(int n);
-/* 1: the epilogue-parameter LDS segments are requested after the prologue's tiles instead of before them (A/B knob) */
-void cfgpp_igemm_set_par_late(int on);
 /* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */
 void cfgpp_igemm_set_split_tile(int cfg);
 /* diagnostics: with a forced config, K-split every tile of a plain-store launch this many ways (0 = off) */

@@ -19,7 +19,6 @@ name, rows = sys.argv[1], int(sys.argv[2])
 wanted = sys.argv[3:]
 lib = _lib.load()
 lib.cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))
-lib.cfgpp_igemm_set_par_late(int(os.environ.get("PAR_LATE", "0")))
 lib.cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))
 eng = HipEngine(name, max_batch=rows // 2)
 cfg, B = eng.cfg, rows // 2
@@ -83,3 +82,18 @@ for want in wanted:
                   ("epilogue (-> stores done)", epi_c), ("workgroup total", tot)):
         print(f"   {nm:50s} cycles p10 {pct(a, 10):9.0f}  p50 {pct(a, 50):9.0f}  p90 {pct(a, 90):9.0f}  max {a.max():9.0f}   (p50 = {pct(a, 50) / ghz / 1e3:.2f} us)")
     print(f"   workgroups per XCC id: {np.bincount(xcc.astype(np.int64), minlength=8).tolist()}")
+    # workgroup turnover per CU: HW_ID bits 8..15 = (cu, sh, se) inside the XCC; s_memrealtime ticks are 10 ns
+    hw = buf[:grid, 6].cpu().numpy()[ok] & 0xFFFFFFFF
+    cu = (xcc.astype(np.int64) << 8) | ((hw.astype(np.int64) >> 8) & 0xFF)
+    gaps, per_cu = [], []
+    for key in np.unique(cu):
+        sel = np.where(cu == key)[0]
+        order = sel[np.argsort(rt0[sel])]
+        per_cu.append(len(order))
+        for x, y in zip(order[:-1], order[1:]):
+            gaps.append((rt0[y] - rt1[x]) * 0.01)
+    busy = float(((rt1 - rt0) * 0.01).sum()) / (len(per_cu) * max(span_us, 1e-9))
+    print(f"   CUs seen {len(per_cu)} (workgroups per CU min {min(per_cu)} max {max(per_cu)}); resident-workgroup time / (CUs x span) = {busy:.2f}")
+    if gaps:
+        g = np.array(gaps)
+        print(f"   exit -> next entry on the same CU (us): p10 {pct(g, 10):.2f} p50 {pct(g, 50):.2f} p90 {pct(g, 90):.2f}  (negative = two workgroups resident)")

@@ -15,8 +15,6 @@ _lib.load().cfgpp_igemm_set_tune_mask(int(os.environ.get("TUNE_MASK", "0xfffffff
 _lib.load().cfgpp_igemm_set_big_split(int(os.environ.get("BIG_SPLIT", "0")))
 _lib.load().cfgpp_layernorm_set_rows_per_wave(int(os.environ.get("LN_RPW", "0")))
 _lib.load().cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))       # 1: head-major epilogue of that tile (unvalidated)
-if os.environ.get("PAR_LATE", "") != "":
-    _lib.load().cfgpp_igemm_set_par_late(int(os.environ["PAR_LATE"]))
 _lib.load().cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))     # > 1: also 2 .. n full rounds of 256 tiles
 _lib.load().cfgpp_igemm_set_mf16(int(os.environ.get("MF16", "4")))                 # 3 / 4: 16x16x32-MFMA 128x160 tile by rule
 _lib.load().cfgpp_igemm_set_split_tile(int(os.environ.get("SPLIT_TILE", "14")))

@@ -128,7 +128,7 @@ def t_conv(N=2, Cin=64, Cout=128, Hh=12, Ww=10):
 def t_conv_temb_small():
     """time-embedding epilogue on feature maps under 8 x 8 (a tile's rows span many batches: the launcher sizes the LDS
     parameter segments for every batch a tile touches, or drops to the 64 x 64 tile when they do not fit), for every tile
-    family and both parameter-staging orders"""
+    family"""
     out = {}
     for (N, Hh, Ww, Cout) in ((40, 4, 4, 320), (70, 2, 2, 320), (9, 2, 3, 128), (3, 8, 8, 320)):
         Cin = 64
@@ -138,14 +138,11 @@ def t_conv_temb_small():
         temb = rnd(N, Cout, scale=0.5, seed=303 + N)
         res = rnd(N, Cout, Hh, Ww, seed=304 + N)
         ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
-        for late in (0, 1):
-            H.lib().cfgpp_igemm_set_par_late(late)
-            for c in (0, 1, 3, 4, 5, 6, 7, 11, 14, 19):
-                H.lib().cfgpp_igemm_force_config(c)
-                got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), Hh, Ww, 1, temb.to(H.DEV), Cout, H.to_pn(res))
-                out[f"n{N}_{Hh}x{Ww}_cfg{c}_late{late}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
+        for c in (0, 1, 3, 4, 5, 6, 7, 11, 14, 19):
+            H.lib().cfgpp_igemm_force_config(c)
+            got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), Hh, Ww, 1, temb.to(H.DEV), Cout, H.to_pn(res))
+            out[f"n{N}_{Hh}x{Ww}_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
     H.lib().cfgpp_igemm_force_config(0)
-    H.lib().cfgpp_igemm_set_par_late(0)
     return out
 
 
