@@ -30,8 +30,11 @@ class HipEngine:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.cfg = cfg
         self.max_batch = int(max_batch)
-        with torch.cuda.device(self.device):          # the caller's current device is left as it was
-            self.unet = E.HipUNet(cfg, max_rows=2 * self.max_batch, sample_hw=latent_hw, device=self.device.index)
+        # One device per process (the torchrun layout; cfgpp_unet_create / cfgpp_vae_create refuse a second one): the engine's
+        # device BECOMES the process's current device and stays it - cfgpp_unet_finalize, the lazily allocated K-split
+        # workspace and every launch run against the current device, and none of the C entry points carries a device guard.
+        torch.cuda.set_device(self.device)
+        self.unet = E.HipUNet(cfg, max_rows=2 * self.max_batch, sample_hw=latent_hw, device=self.device.index)
         if weights == "synthetic":
             items = synth_state_dict_iter(cfg, weight_seed)
         elif isinstance(weights, str):

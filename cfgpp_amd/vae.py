@@ -134,6 +134,7 @@ class HipVAE:
         self.h, self.w = int(latent_hw[0]), int(latent_hw[1])
         self.max_batch = int(max_batch)
         self._sd = state_dict if state_dict is not None else synth_vae_state_dict(seed)
+        torch.cuda.set_device(self.device)      # one device per process: the engine's device is the current device (see HipEngine)
         self._h = self.lib.cfgpp_vae_create(self.h, self.w, self.max_batch, self.scaling_factor, self.device.index)
         if not self._h:
             raise CfgppError("cfgpp_vae_create failed: " + _lib.last_error())
