@@ -1,0 +1,67 @@
+"""CPU checks of the two index-math claims the round-3 epilogues rest on (cfgpp_amd/csrc/igemm_kernel.hip):
+
+* ``qdiv``: floor(m / d) as one multiply by an fp32 reciprocal plus a one-step correction is EXACT for quotients below
+  2^20, even when the hardware reciprocal (v_rcp_f32, 1 ulp) is off by two ulps;
+* ``head_col`` / ``head_step``: (part, head, offset in the head) of a column computed once per aligned column group plus
+  at most one conditional wrap equals the per-column ``n / part_width``, ``(n % part_width) / head_dim``,
+  ``(n % part_width) % head_dim`` the epilogues used to evaluate per 16-byte piece.
+"""
+import numpy as np
+import pytest
+
+
+def _qdiv(m, d, ulps):
+    inv = np.float32(1.0) / np.float32(d)
+    for _ in range(abs(ulps)):
+        inv = np.nextafter(inv, np.float32(np.inf if ulps > 0 else -np.inf))
+    q = (m.astype(np.float32) * inv).astype(np.int64)          # v_cvt_f32_i32, v_mul_f32, v_cvt_i32_f32 (truncation)
+    r = m - q * d
+    return q + (r >= d).astype(np.int64) - (r < 0).astype(np.int64)
+
+
+@pytest.mark.parametrize("ulps", [-2, -1, 0, 1, 2])
+def test_reciprocal_division_is_exact_for_small_quotients(ulps):
+    rng = np.random.default_rng(7 + ulps)
+    # divisors: H*W of every level (and odd ones), image widths, tile-walk divisors
+    divisors = [1, 2, 3, 4, 5, 6, 7, 9, 10, 12, 16, 20, 24, 25, 36, 48, 63, 64, 65, 77, 96, 100, 128, 255, 256, 257, 1000, 1024,
+                4096, 4097, 16384, 65536, 262144, 1048576, 1023 * 1025]
+    for d in divisors:
+        qmax = min(2 ** 20, (2 ** 31 - 1) // d)
+        q = rng.integers(0, qmax, 60000)
+        r = rng.integers(0, d, 60000)
+        r[:20000] = 0                                           # exact multiples and the value just below them
+        r[20000:40000] = d - 1
+        m = q * d + r
+        m = m[m < 2 ** 31 - 1]
+        assert np.array_equal(_qdiv(m, d, ulps), m // d), d
+
+
+def _head_step(dd0, head0, off, head_dim):
+    dd, head = dd0 + off, head0
+    if head_dim >= 32:
+        if dd >= head_dim:
+            dd -= head_dim
+            head += 1
+    else:
+        head += dd // head_dim
+        dd = dd % head_dim
+    return head, dd
+
+
+@pytest.mark.parametrize("group", [16, 32])
+@pytest.mark.parametrize("head_dim", [8, 16, 40, 64, 80, 160])
+def test_head_major_addressing_without_per_piece_divisions(group, head_dim):
+    for heads in (1, 2, 5, 8, 20):
+        part_width = heads * head_dim
+        if part_width % group:
+            continue                                            # the staged epilogues require aligned parts
+        N = 3 * part_width
+        for ng in range(0, N, group):                           # first column of an aligned group (wave-uniform)
+            pr = ng // part_width
+            cn0 = ng - pr * part_width
+            head0, dd0 = cn0 // head_dim, cn0 % head_dim
+            for off in range(group):
+                n = ng + off
+                cn = n % part_width
+                assert n // part_width == pr                    # a group lies inside one part
+                assert _head_step(dd0, head0, off, head_dim) == (cn // head_dim, cn % head_dim), (ng, off)
