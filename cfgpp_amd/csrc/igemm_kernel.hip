@@ -1669,7 +1669,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     // to_out K = 1280 436 -> 505, SD1.5 forward 21.06 -> 20.61 ms (profiles/r02/ab/igemm_mf16_run9.txt).
     if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a)) {
         const long t7 = (long)cdiv(a.M, 128) * (a.N / 160);
-        // (g_mf16_rounds > 1: also grids of exactly 2 .. g_mf16_rounds full rounds - an A/B knob, default 1)
+        // (also grids of exactly 2 .. g_mf16_rounds full rounds; default 2, see g_mf16_rounds)
         const bool full_rounds = t7 > 256 && t7 % 256 == 0 && t7 / 256 <= g_mf16_rounds;
         if ((t7 >= 200 && t7 <= 256) || full_rounds) return launch_config(g_mf16 == 4 ? 19 : 18, a, stream);
     }
