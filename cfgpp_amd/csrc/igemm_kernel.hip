@@ -75,12 +75,6 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
     return (b * (H + 2) + y + 1) * (W + 2) + x + 1;
 }
 
-// fused LayerNorm (IGemmArgs::ln_stats): (mean, rstd) of GEMM row m, or (0, 1) when the launch has none
-__device__ __forceinline__ float2 ln_row(const IGemmArgs& p, int m) {
-    if (p.ln_stats == nullptr) return make_float2(0.f, 1.f);
-    const int mc = m < p.M ? m : p.M - 1;
-    return *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mc);
-}
 
 // ---- epilogue parameters in LDS -----------------------------------------------------------------------------------------
 // The per-column parameters of an epilogue (bias, per-batch time embedding, LayerNorm column sums) used to be read from
@@ -97,9 +91,27 @@ __host__ __device__ constexpr int par_bytes(int BN, int nb = PAR_NB) { return pa
 struct Par {
     const char* lds;     // null: read the parameters from global memory (register-staged kernels, the K-split reduce kernel)
     int n0, b0, bnp;     // first column / first batch of the tile, padded segment length (floats)
+    const char* rows;    // fused LayerNorm: (mean, rstd) of the tile's BM rows, staged behind the column segments
+    int m0;              // first row of the tile
 };
+// bytes of the column segments = offset of the row segment (the launcher sizes the same way)
+__device__ __forceinline__ int par_rows_off(const IGemmArgs& p, int BN) {
+    return par_bnp(BN) * 4 * (2 + (p.par_nb > PAR_NB ? p.par_nb : PAR_NB));
+}
+// fused LayerNorm (IGemmArgs::ln_stats): (mean, rstd) of GEMM row m, or (0, 1) when the launch has none.  L: from the LDS row
+// segment (a per-row global load here sat in its own branch = one serialised memory round trip per 32-row sub-tile: the
+// +7..18 % the consumer epilogues cost in the first LayerNorm-fusion A/B, profiles/r03/ab/ln_fusion.txt)
+template <bool L>
+__device__ __forceinline__ float2 ln_row(const IGemmArgs& p, const Par& q, int m) {
+    if (p.ln_stats == nullptr) return make_float2(0.f, 1.f);
+    if constexpr (L) return *reinterpret_cast<const float2*>(q.rows + (m - q.m0) * 8);
+    else {
+        const int mc = m < p.M ? m : p.M - 1;
+        return *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mc);
+    }
+}
 // issue the DMA pieces (64 floats each) of the tile's parameter segments; NW = waves of the workgroup
-template <int BN, int NW>
+template <int BN, int NW, int BM>
 __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0, int m0, int wid, int lane) {
     constexpr int BNP = par_bnp(BN), NPC = BNP / 64;
     int nn = n0 + lane;                                     // + 64 * piece, clamped per piece
@@ -119,7 +131,21 @@ __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0,
         }
     };
     if (p.bias) arr(p.bias, 0);
-    if (p.ln_stats) arr(p.ln_c, 1);
+    if (p.ln_stats) {
+        arr(p.ln_c, 1);
+        // (mean, rstd) of rows m0 .. m0 + BM - 1: BM * 2 floats = BM / 32 pieces
+        char* rows = par + par_rows_off(p, BN);
+        const int last = 2 * p.M - 1;
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q, ++pi) {
+            if (wid == pi % NW) {
+                int d = 2 * m0 + 64 * q + lane;
+                d = d < last ? d : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_stats + d),
+                                                 (__attribute__((address_space(3))) void*)(rows + q * 256), 4, 0, 0);
+            }
+        }
+    }
     if (p.temb) {
         for (int k = 0; k < p.par_nb; ++k) {               // (run-time count: 2 .. 5 for H*W >= 64)
             int b = b0 + k;
@@ -170,7 +196,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         if (m >= p.M) continue;
         const int b = (HW > 0) ? qdiv(m, HW) : 0;
         const int tok = m - b * HW;
-        const float2 lnst = ln_row(p, m);
+        const float2 lnst = ln_row<L>(p, par, m);
         long orow = m, rrow = m;
         if (p.omode == 1 || p.rmode == 1) {
             const long pp = padded_pix(m, HW, p.W, p.H);
@@ -371,7 +397,7 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
     const int NF = p.N >> 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const float2 lnst = ln_row(p, mw0 + i * 32 + frow);
+        const float2 lnst = ln_row<L>(p, par, mw0 + i * 32 + frow);
 #pragma unroll
         for (int j = 0; j < NT; j += 2)
 #pragma unroll
@@ -451,7 +477,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
         const int m0s = __builtin_amdgcn_readfirstlane(mw0 + i * 32);   // first token row of the sub-tile (multiple of 32)
         if (m0s >= p.M) continue;
         const int b = qdiv(m0s, HW), tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
-        const float2 lnst = ln_row(p, m0s + frow);
+        const float2 lnst = ln_row<L>(p, par, m0s + frow);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ng = nw0 + j * 32;                       // first column of the 32-column group
@@ -718,7 +744,7 @@ igemm_kernel(const IGemmArgs p) {
         // the parameter segments are the oldest loads of the kernel: covered by every counted wait.  (Requesting them AFTER the
         // prologue's tiles instead - conservative counted waits, published by the loop's draining waits - measured the same
         // in situ, profiles/r03/ab/par_late_ln_fusion_call6.txt, and the second copy of par_stage cost the 256 x 320 kernel 100 spills.)
-        if (!is_tail) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
+        if (!is_tail) par_stage<BN, WM * WN, BM>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
         tl_stamp(p.tl, 9);
@@ -930,6 +956,7 @@ igemm_kernel(const IGemmArgs p) {
     }
     Par par;
     par.lds = GLDS ? smem + PAR_OFF : nullptr; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
+    par.rows = GLDS ? smem + PAR_OFF + par_rows_off(p, BN) : nullptr; par.m0 = m0;
     constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
     if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
@@ -989,7 +1016,7 @@ igemm_reduce_kernel(const IGemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += base[sidx * sstride + (long)r * NTHR];
     }
-    Par par; par.lds = nullptr; par.n0 = 0; par.b0 = 0; par.bnp = 0;      // parameters from global memory
+    Par par; par.lds = nullptr; par.n0 = 0; par.b0 = 0; par.bnp = 0; par.rows = nullptr; par.m0 = 0;      // parameters from global memory
     igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par);
 }
 
@@ -1106,7 +1133,7 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     for (int j = 0; j < 5; ++j) hc[j] = head_col(p, nw0 + j * 16);
     float2 lnst[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) lnst[i] = ln_row(p, mw0 + i * 16 + c16);
+    for (int i = 0; i < 2; ++i) lnst[i] = ln_row<L>(p, par, mw0 + i * 16 + c16);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ng = nw0 + j * 16;                           // first column of the 16-column group (ng < N: N % 160 == 0)
@@ -1277,7 +1304,7 @@ igemm16_kernel(const IGemmArgs p) {
     const int nk = p.K >> 6;
     tl_stamp(p.tl, 8);
     constexpr int PAR_OFF = NST * STAGE_BYTES;      // epilogue parameters behind the ring
-    par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
+    par_stage<BN, 8, BM>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1374,6 +1401,7 @@ igemm16_kernel(const IGemmArgs p) {
 
     Par par;
     par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
+    par.rows = smem + PAR_OFF + par_rows_off(p, BN); par.m0 = m0;
     if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536), par);
     else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176), par);
     tl_end(p.tl);
@@ -1410,13 +1438,13 @@ static int par_slots(const IGemmArgs& a, int BM) {
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem_std = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) : 0);      // ring + epilogue-parameter segments
+    constexpr int smem_std = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) + BM * 8 : 0);      // ring + epilogue-parameter segments (columns, rows)
     static_assert(smem_std <= 160 * 1024, "tile does not fit the LDS");
     constexpr int blocks_per_cu = (160 * 1024) / smem_std < 8 ? (160 * 1024) / smem_std : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     IGemmArgs a = a_in;
     a.par_nb = par_slots(a, BM);
-    const int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) : 0);
+    const int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) + BM * 8 : 0);
     if (smem > 160 * 1024) {
         // feature maps under 8 x 8 with a time embedding (images under 64 px per side at the bottom level): a big tile spans more
         // batches than its LDS can stage rows for - the 64 x 64 tile (<= 66 rows of 64 floats) always fits
@@ -1497,7 +1525,7 @@ template <int AMODE, int NST>
 int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.par_nb = par_slots(a, 128);
-    const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB);
+    const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) + 128 * 8;
     if (smem > 160 * 1024) return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2>(a_in, stream);   // (feature maps under 8 x 8: see launch_cfg_amode)
     static int attr_smem = 0;
     auto kern = igemm16_kernel<AMODE, NST>;
