@@ -262,8 +262,9 @@ int cfgpp_op_igemm_heads_ln(const void* a, int K, const void* w, int M, int N, c
                             int head_dim, int heads, int q_tok_pad, int tok_pad, void* stream);
 int cfgpp_op_geglu_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
                       const float* ln_c, void* out, void* stream);
-/* 1 (default): UNet engines finalized after this call fold the transformer blocks' LayerNorms into the projections that
- * consume them; 0: separate layernorm launches (A/B, fallback) */
+/* 1: UNet engines finalized after this call fold the transformer blocks' LayerNorms into the projections that consume
+ * them (same function, different fp16 rounding points; measured neutral in situ, profiles/r03/ab/ln_fusion*.txt);
+ * 0 (default): separate layernorm launches */
 void cfgpp_unet_set_fuse_ln(int on);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
