@@ -289,7 +289,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // generic igemm op helpers ----------------------------------------------------
 IGemmArgs base_args() {
-    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; return a;
+    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; a.ln_eps = 1e-5f; return a;
 }
 
 struct Plan {

@@ -46,7 +46,9 @@ struct cfgpp_unet : EngineBase {
 // 4 rows: 2.36 -> 1.56 ms per forward), but both are latency-bound launches, and the consumers' epilogues paid the saving back
 // (+0.98 ms) - so it stays opt-in until the statistics come out of the PRODUCING GEMM's epilogue and the launches disappear.
 static int g_fuse_ln = 0;
-extern "C" void cfgpp_unet_set_fuse_ln(int on) { g_fuse_ln = on ? 1 : 0; }
+// 0 = LayerNorm kernels; 1 = folded into the consuming projection, (mean, rstd) from a statistics pass; 2 = folded in, the
+// consuming kernel derives (mean, rstd) from its own operand fragments in the K loop (no statistics launch at all)
+extern "C" void cfgpp_unet_set_fuse_ln(int on) { g_fuse_ln = on == 2 ? 2 : on ? 1 : 0; }
 
 namespace {
 
@@ -394,9 +396,10 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             }
             ++cross_block_counter;
             // self-attention
+            float* const stats = g_fuse_ln == 2 ? nullptr : u->tok_stats;      // null: the consumer takes them in its K loop
             if (fuse) {
-                P.ln_stats(u->tok_x, u->tok_stats, tok, C);
-                P.heads(u->tok_x, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad, true, d1, u->tok_stats, c1);
+                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
+                P.heads(u->tok_x, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad, true, d1, stats, c1);
             } else {
                 P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
                 P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
@@ -405,8 +408,8 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             P.linear(u->tok_attn, C, u->tok_x, C, wo1, bo1, u->tok_x, tok);
             // cross-attention
             if (fuse) {
-                P.ln_stats(u->tok_x, u->tok_stats, tok, C);
-                P.heads(u->tok_x, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad, true, d2, u->tok_stats, c2);
+                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
+                P.heads(u->tok_x, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad, true, d2, stats, c2);
             } else {
                 P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
                 P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
@@ -423,8 +426,8 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
             // feed-forward (GEGLU)
             if (fuse) {
-                P.ln_stats(u->tok_x, u->tok_stats, tok, C);
-                P.linear(u->tok_x, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU, u->tok_stats, c3);
+                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
+                P.linear(u->tok_x, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU, stats, c3);
             } else {
                 P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
                 P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);

@@ -255,7 +255,8 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 /* the head-major projection / the GEGLU projection with a LayerNorm of the input rows folded in: a = UN-normalised rows,
  * w = W * gamma (per input channel), bias = W beta (+ the layer's bias), ln_c[n] = sum_k w[n][k], ln_stats = (mean, rstd) per
- * row from cfgpp_op_ln_stats; the epilogue forms rstd * (acc - mean * ln_c) + bias.  Same output contracts as
+ * row from cfgpp_op_ln_stats, or NULL: the kernel accumulates sum / sum of squares of its rows from the activation fragments of
+ * its K loop (eps 1e-5); the epilogue forms rstd * (acc - mean * ln_c) + bias.  Same output contracts as
  * cfgpp_op_igemm_heads / cfgpp_op_igemm with epi = 1 (w and bias in the packed GEGLU order). */
 int cfgpp_op_igemm_heads_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
                             const float* ln_c, int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width,
@@ -263,7 +264,8 @@ int cfgpp_op_igemm_heads_ln(const void* a, int K, const void* w, int M, int N, c
 int cfgpp_op_geglu_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
                       const float* ln_c, void* out, void* stream);
 /* 1: UNet engines finalized after this call fold the transformer blocks' LayerNorms into the projections that consume
- * them (same function, different fp16 rounding points; measured neutral in situ, profiles/r03/ab/ln_fusion*.txt);
+ * them, (mean, rstd) per row from a statistics pass; 2: folded in, and the consuming kernel takes (mean, rstd) from its own
+ * operand fragments in the K loop - no statistics launch (same function as 0, different fp16 rounding points);
  * 0 (default): separate layernorm launches */
 void cfgpp_unet_set_fuse_ln(int on);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,

@@ -370,7 +370,8 @@ def t_ln_fused():
         out[f"stats_mean_c{C}"] = H.err_stats(st[:, 0], x.mean(1))
         out[f"stats_rstd_c{C}"] = H.err_stats(st[:, 1], (x.var(1, unbiased=False) + 1e-5).rsqrt())
     # heads
-    for (B, tokens, C, nheads, cfgs) in ((2, 96, 320, 8, (0, 7, 18, 19)), (2, 160, 128, 4, (0, 1, 7, 14))):
+    for (B, tokens, C, nheads, cfgs) in ((2, 96, 320, 8, (0, 7, 18, 19)), (2, 160, 128, 4, (0, 1, 7, 14)),
+                                         (3, 128, 1280, 20, (0, 1, 4, 5, 6, 7, 8, 11, 12, 14, 18, 19))):
         d = C // nheads
         x = (rnd(B * tokens, C, seed=40) * 1.5 + rnd(B * tokens, 1, seed=41) * 3).half().float()        # per-row offsets: mean != 0
         w = rnd(3 * C, C, scale=C ** -0.5, seed=42)
@@ -386,8 +387,13 @@ def t_ln_fused():
             out[f"q_c{C}_cfg{cf}"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
             out[f"k_c{C}_cfg{cf}"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
             out[f"vt_c{C}_cfg{cf}"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+            # the same launch with NO statistics buffer: the kernel takes (mean, rstd) from its own fragments in the K loop
+            hq, hk, hvt = H.heads_project_ln(xd, wp, c, dd, None, B, tokens, C, nheads, 0, qp, kp)
+            out[f"q_c{C}_cfg{cf}_inline"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+            out[f"k_c{C}_cfg{cf}_inline"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
+            out[f"vt_c{C}_cfg{cf}_inline"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
     # GEGLU
-    for (M, C, cfgs) in ((520, 320, (0, 1, 4, 10)), (300, 64, (0, 1))):
+    for (M, C, cfgs) in ((520, 320, (0, 1, 4, 10)), (300, 64, (0, 1)), (700, 1280, (0, 1, 4, 6, 10, 12, 14))):
         x = (rnd(M, C, seed=50) * 1.5 + rnd(M, 1, seed=51) * 3).half().float()
         w = rnd(8 * C, C, scale=C ** -0.5, seed=52)
         b = rnd(8 * C, scale=0.1, seed=53)
@@ -401,6 +407,7 @@ def t_ln_fused():
         for cf in cfgs:
             H.lib().cfgpp_igemm_force_config(cf)
             out[f"geglu_c{C}_cfg{cf}"] = H.err_stats(H.geglu_ln(xd, wp, c, dd, st), ref)
+            out[f"geglu_c{C}_cfg{cf}_inline"] = H.err_stats(H.geglu_ln(xd, wp, c, dd, None), ref)
     H.lib().cfgpp_igemm_force_config(0)
     return out
 
