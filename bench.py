@@ -322,7 +322,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
         hints = None
         if rank == 0:
             one_job()
-            torch.cuda.synchronize()
+            sync(dev)
             hints = eng.unet.export_tuning(2 * B)
         hints = D.broadcast_ints(hints, dev)
         if rank != 0 and hints:
@@ -330,17 +330,17 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
         tuning = f"rank 0's {len(hints)} pins broadcast to all ranks"
     for i in range(warmup):
         out = one_job()
-        torch.cuda.synchronize()
+        sync(dev)
         log(f"warmup job {i} done")
     D.barrier()
-    torch.cuda.synchronize()
+    sync(dev)
     job_s = []
     t0 = time.perf_counter()
     for _ in range(steps):
         tj = time.perf_counter()
         out = one_job()                      # returns host images: the D2H copy at its end is the job's own sync point
         job_s.append(time.perf_counter() - tj)
-    torch.cuda.synchronize()
+    sync(dev)
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
     log(f"timed region done: {dt:.2f}s for {steps} jobs")
@@ -352,7 +352,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     n_unet = nfe * (2 if "inversion" in name else 1)
     rows = 2 * B
     unet_flops = eng.flops_per_forward(rows)          # algorithmic, per forward at this batch
-    flops_per_image = (n_unet * unet_flops / B) + VAE_DEC_FLOPS[img] + (VAE_ENC_FLOPS[img] if "inversion" in name else 0.0)
+    flops_per_image = (n_unet * unet_flops / B) + VAE_DEC_FLOPS.get(img, 0.0) + (VAE_ENC_FLOPS.get(img, 0.0) if "inversion" in name else 0.0)
     flat = [x for r in per_rank for x in r]
     result = {
         "metric": "images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": steps,
@@ -380,23 +380,59 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     return result
 
 
-def main():
-    args = parse()
-    from cfgpp_amd import dist as D
-    rank, local_rank, world = D.init()
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+def device_for(local_rank):
+    """the rank's GPU (tests/bench_mock_main.py replaces this and make_solver to run the same main() on CPU + gloo)"""
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank-local device {local_rank} requested but only {torch.cuda.device_count()} GPUs are visible")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    return dev
+
+
+def sync(dev):
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no torchrun environment): start the N ranks ourselves -
+    re-exec this very command under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1 - and exit with
+    its status.  Rank 0 of the child job prints the JSON line on the inherited stdout.  Returns only when the process
+    already is a rank (or N == 1)."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    log(f"--gpus {args.gpus} without a launcher environment: starting {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def main():
+    args = parse()
+    self_launch(args)
+    from cfgpp_amd import dist as D
+    rank, local_rank, world = D.init()
+    if world != args.gpus:
+        # never a silent 1-GPU run under an N-GPU label (or the reverse)
+        raise SystemExit(f"--gpus {args.gpus} but the job has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')})")
+    dev = device_for(local_rank)
     result = run_workload(args, args.config, rank, world, dev, args.steps, args.warmup, args.batch, args.nfe)
     if args.config == "sd15" and not args.no_also and not args.batch and not args.nfe:
         # BASELINE.json's metric names SD1.5 512^2 AND SDXL 1024^2: the default command also times a short SDXL leg
         # (configs[2]'s per-GPU share: batch 2 per GPU, 50 NFE) - 1 warm-up job (in-situ tuning) + 2 timed jobs
         import gc
         gc.collect()
-        torch.cuda.empty_cache()
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
         log("also: SDXL 1024x1024 leg")
         try:
             xl = run_workload(args, "sdxl", rank, world, dev, 2, 1, with_cpu_baseline=False)

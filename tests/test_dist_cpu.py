@@ -131,3 +131,37 @@ def test_world2_bench_flow_equals_single_process():
         assert res[1][kind][0] is None and total == 4 and dt == res[1][kind][2] == 1.5
         ref, _ = _bench_flow(kind, 0, 1, 4)      # world 1, the whole global batch in one process
         assert torch.equal(torch.from_numpy(got), ref), kind
+
+
+# ---- `python bench.py --gpus N` started without a launcher must start N ranks itself ----
+def _run_mock_bench(argv, env_extra=None, timeout=600):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    env["CFGPP_BENCH_VERBOSE"] = "0"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_mock_main.py")] + argv, capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_gpus2_self_launches_two_ranks():
+    """the driver's command line, no torchrun around it: bench.main() re-executes itself under torch.distributed.run with two
+    ranks (gloo here, RCCL on the GPU box) and rank 0 prints ONE JSON line that says n_gpus 2 and carries both ranks' job times"""
+    import json
+    p = _run_mock_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "mock", "--no-profile", "--no-cpu-baseline", "--no-also"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 2 * r["config"]["per_gpu_batch"]
+    assert len(r["ranks"]["job_ms_mean_per_rank"]) == 2
+    assert "3 pins broadcast" in r["ranks"]["tile_tuning"]
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    """--gpus 2 inside a 1-rank launcher environment (or the reverse) is refused, never a silently mislabelled run"""
+    p = _run_mock_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "mock", "--no-profile", "--no-cpu-baseline", "--no-also"],
+                        env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "--gpus 2 but the job has 1 rank" in (p.stderr + p.stdout)
