@@ -337,7 +337,8 @@ class StableDiffusion:
             noise_uc, noise_c = self.predict_noise(xc, new_t, uc, c)
             if (not two_stage) or float(sigma_down) == 0.0:
                 # Euler step down to sigma_down: x = den + ((x - d_from)/sigma) * sigma_down
-                coef = [float(lam), float(sigma), 0.0, float(sigma.item()), float(sigma_down), 0.0, 0.0, 1.0, 0.0]
+                # (`/ sigma.item()` in to_d, latent_diffusion.py:216-218, is a python-number divisor: K.divisor applies the backend rule)
+                coef = [float(lam), float(sigma), 0.0, K.divisor(sigma.item(), sem), float(sigma_down), 0.0, 0.0, 1.0, 0.0]
                 self.engine.step_kdiff(x, den, None, noise_uc, noise_c, coef, variant, False, True, False)
             else:
                 self.engine.kdiff_denoise(x, noise_uc, noise_c, lam, float(sigma), den, uden)

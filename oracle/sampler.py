@@ -183,7 +183,7 @@ def _sub(a, b):
     return _f(a) - _f(b)
 
 
-def kdiff_denoised(x, eps_uc, eps_c, lam, sigma, xl_form: bool = False):
+def kdiff_denoised(x, eps_uc, eps_c, lam, sigma, xl_form: bool = False, semantics: str = "cpu"):
     """SD1.5 (latent_diffusion.py:232-241): ``denoised = x - eps_hat*sigma``,
     ``uncond_denoised = x - eps_uc*sigma`` (tensor first -> fp32 sigma).
     SDXL 2M (latent_sdxl.py:895-906, ``xl_form``): ``x + c_out*eps`` with
@@ -191,18 +191,19 @@ def kdiff_denoised(x, eps_uc, eps_c, lam, sigma, xl_form: bool = False):
     eps_hat = cfg_mix(eps_uc, eps_c, lam)
     if xl_form:
         c_out = -_s(sigma)
-        den = _add(x, _smul_first(c_out, eps_hat))
-        uden = _add(x, _smul_first(c_out, eps_uc))
+        den = _add(x, _smul_first(c_out, eps_hat, semantics))
+        uden = _add(x, _smul_first(c_out, eps_uc, semantics))
     else:
         den = _sub(x, _mul_s(eps_hat, sigma))
         uden = _sub(x, _mul_s(eps_uc, sigma))
     return den, uden
 
 
-def euler_step(x, den, d_from, sigma, sigma_next):
+def euler_step(x, den, d_from, sigma, sigma_next, semantics: str = "cpu"):
     """x' = den + ((x - d_from)/sigma.item()) * sigma_next
-    (latent_diffusion.py:708-710; ``d_from`` = uncond_denoised for CFG++, den for CFG)."""
-    d = _div_s(_sub(x, d_from), float(sigma))
+    (latent_diffusion.py:708-710; ``d_from`` = uncond_denoised for CFG++, den for CFG).  ``/ sigma.item()`` is a division by
+    a python number: IEEE on torch-CPU, a multiply by the host-side fp32 reciprocal on a GPU (``semantics``, see _div_s)."""
+    d = _div_s(_sub(x, d_from), float(sigma), semantics)
     return _add(den, _mul_s(d, sigma_next))
 
 
@@ -219,7 +220,7 @@ def dpm2m_coeffs(sigmas, i):
     return out
 
 
-def dpm2m_step(x, den, uden, old, sigmas, i, variant: str):
+def dpm2m_step(x, den, uden, old, sigmas, i, variant: str, semantics: str = "cpu"):
     """One DPM-Solver++(2M) update on an fp16 (or fp32) latent.
 
     variant "cfg"      : latent_diffusion.py:482-490  (extra uses den, old=den)
@@ -232,16 +233,16 @@ def dpm2m_step(x, den, uden, old, sigmas, i, variant: str):
     first = old is None or float(sig_next) == 0.0
     d_from = den if variant == "cfg" else uden
     if first:
-        xn = euler_step(x, den, d_from, sig, sig_next)
+        xn = euler_step(x, den, d_from, sig, sig_next, semantics)
     else:
         c = dpm2m_coeffs(sigmas, i)
         lead = den if variant == "cfg" else uden           # multiplied by -exp(-h)
         diff_a = uden if variant == "cfgpp_xl" else den     # (diff_a - old)
         # extra1 = -exp(-h)*lead - expm1(-h) * (diff_a - old) / (2r)
-        term1 = _smul_first(-c["exp_mh"], lead)
-        term2 = _div_s(_smul_first(c["expm1_mh"], _sub(diff_a, old)), 2 * c["r"])
+        term1 = _smul_first(-c["exp_mh"], lead, semantics)
+        term2 = _div_s(_smul_first(c["expm1_mh"], _sub(diff_a, old), semantics), 2 * c["r"], semantics)
         extra1 = _sub(term1, term2)
-        extra2 = _smul_first(c["exp_mh"], x)
+        extra2 = _smul_first(c["exp_mh"], x, semantics)
         xn = _add(_add(den, extra1), extra2)
     new_old = den if variant == "cfg" else uden
     return xn, new_old

@@ -137,6 +137,40 @@ def test_kdiff_steps_equal_torch_rocm_on_the_references_expressions(E, variant, 
     assert bad == 0, f"variant {variant} xl_form={xl_form}: elements differing from torch-ROCm per step (i, (xc, denoised, x, old)): {detail}"
 
 
+@pytest.mark.parametrize("cfgpp", [False, True])
+def test_ancestral_euler_step_equals_torch_rocm_on_the_references_expressions(E, cfgpp):
+    """euler_a / euler_a_cfg++ (latent_diffusion.py:349-390, 726-766): ``to_d``'s ``/ sigma.item()`` is a python-number divisor
+    (reciprocal multiply on the GPU) and ``d * sigma_down`` a tensor-first product; the coefficients are the ones
+    ``StableDiffusion._ancestral_loop`` hands to cfgpp_step_kdiff."""
+    from cfgpp_amd import coeffs as K
+    from cfgpp_amd.schedule import get_ancestral_step
+    from cfgpp_amd.schedule import SchedulerTables
+    tb = SchedulerTables(20)
+    sigmas = tb.karras_sigmas()
+    lam = 0.6 if cfgpp else 7.5
+    bad, detail = 0, []
+    for i in (0, 3, 11, 18, 19):
+        sigma = sigmas[i]
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1])
+        x = _rand(SHAPE, 60 + i, float(sigma), torch.float16).cuda()
+        noise_uc, noise_c = (_rand(SHAPE, 70 + 2 * i + j, 1.0, torch.float16).cuda() for j in range(2))
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            noise_pred = noise_uc + lam * (noise_c - noise_uc)
+            denoised = x - noise_pred * sigma
+            uncond_denoised = x - noise_uc * sigma
+            d = (x - (uncond_denoised if cfgpp else denoised)) / sigma.item()
+            xn = denoised + d * sigma_down
+        assert xn.dtype == torch.float16
+        coef = [float(lam), float(sigma), 0.0, K.divisor(sigma.item(), "cuda"), float(sigma_down), 0.0, 0.0, 1.0, 0.0]
+        xk, denk = x.clone(), torch.empty_like(x)
+        E.step_kdiff(xk, denk, None, noise_uc, noise_c, coef, 1 if cfgpp else 0, False, True, False)
+        torch.cuda.synchronize()
+        nb = (int((denk != denoised).sum()), int((xk != xn).sum()))
+        detail.append((i, nb))
+        bad += sum(nb)
+    assert bad == 0, f"cfgpp={cfgpp}: elements differing from torch-ROCm per step (i, (denoised, x)): {detail}"
+
+
 @pytest.mark.parametrize("z_half", [False, True])
 @pytest.mark.parametrize("flow", ["forward_last_step", "inversion_first_step"])
 def test_device_resident_final_alpha(E, flow, z_half):
