@@ -163,15 +163,30 @@ PROFILE_ROUND = "r03"
 def roofline_block(eng, config, B, dev, rnd):
     """Dominant kernel = the implicit-GEMM conv/linear kernel.  `achieved` = algorithmic FLOPs of its launches in one
     UNet forward / their summed HIP-event durations on the launch stream (`cfgpp_unet_profile`: three profiled forwards
-    right after the timed region, per launch the fastest of the three; all three per-family sums are in the JSON line).  Live as well: attention TFLOP/s, and algorithmic GB/s of the HBM-bound families
+    right after the timed region; the MEDIAN pass's family sum is `achieved`, the per-launch minimum over the three passes is
+    reported beside it as `achieved_per_launch_min`; all three per-family sums are in the JSON line).  Live as well: the wall
+    time of whole forwards at the job's batch (`unet_forward_wall_ms`), attention TFLOP/s, and algorithmic GB/s of the HBM-bound families
     (GroupNorm / LayerNorm at 4 B per element, the fused CFG++ step at 16 B per latent element).  From the committed
     rocprofv3 PMC passes of the SAME population (UNet-only forwards at this batch with the tiles this build's tuner
     pins; scripts/pmc_unet.py + scripts/pmc_summary.py -> profiles/<round>/pmc_<config>_b<B>.json): `traffic` (HBM
     bytes per igemm launch, FETCH_SIZE x2 + WRITE_SIZE per the gfx950 note of the guide) and `mfma_util`
     (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)) of the igemm and attention kernels."""
     import re
-    rows = 2 * B
-    z = torch.randn((B, 4, eng.H, eng.W), device=dev)
+    # whole UNet forward at the job's batch (all lanes, as the sampling loop runs it): wall time of back-to-back predict() calls
+    zf = torch.randn((B, 4, eng.H, eng.W), device=dev)
+    for _ in range(2):
+        eng.predict(zf, 500.0)
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    for _ in range(10):
+        eng.predict(zf, 500.0)
+    f1.record()
+    torch.cuda.synchronize()
+    forward_wall_ms = f0.elapsed_time(f1) / 10
+    # per-launch profile: ONE lane's executor alone on its stream (with lanes > 1 it holds rows / lanes of the batch; kernels of
+    # concurrent lanes share the CUs, so event brackets taken while another lane runs would time the mix, not the kernel)
+    rows = eng.unet.rows
+    z = torch.randn((min(B, rows), 4, eng.H, eng.W), device=dev)
     KIND = {"0": "igemm", "1": "attention", "2": "norm", "3": "small"}
     passes, flops, launches = [], {}, {}
     for t in (981.0, 501.0, 21.0):
@@ -235,6 +250,9 @@ def roofline_block(eng, config, B, dev, rnd):
            "mfma_util": None if pmc is None else {k: pmc[k].get("mfma_util") for k in ("igemm", "attention") if k in pmc},
            "achieved_per_launch_min": round(ach_min, 1),
            "launches_per_forward": ig["launches"], "avg_launch_us": round(med["igemm"] / max(ig["launches"], 1) * 1e3, 2),
+           "lanes": getattr(eng, "lanes", 1), "profiled_rows": rows,
+           "unet_forward_wall_ms": round(forward_wall_ms, 3), "unet_forward_rows": 2 * B,
+           "unet_forward_TFLOPs": round(eng.flops_per_forward(2 * B) / (forward_wall_ms * 1e-3) / 1e12, 1),
            "per_family_ms_per_forward": {k: round(v, 3) for k, v in med.items()},
            "per_family_ms_per_launch_min": {k: round(v["ms"], 3) for k, v in fam.items()},
            "per_family_ms_per_profiled_pass": [{k: round(v, 3) for k, v in pm.items()} for pm in pass_ms],
@@ -311,7 +329,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     log(f"building engine {cfg_name} max_batch={B}")
     solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
     eng = solver.engine
-    log(f"engine ready, device memory {eng.unet.device_bytes() / 1e9:.2f} GB")
+    log(f"engine ready, {getattr(eng, 'lanes', 1)} lane(s), device memory {eng.device_bytes() / 1e9:.2f} GB")
 
     one_job, total = prepare_job(solver, cfg, kind, name, B, img, lam, rank, world, dev)
     broadcast_ms = getattr(prepare_job, "broadcast_ms", 0.0)
@@ -323,10 +341,10 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
         if rank == 0:
             one_job()
             sync(dev)
-            hints = eng.unet.export_tuning(2 * B)
+            hints = eng.export_tuning()
         hints = D.broadcast_ints(hints, dev)
         if rank != 0 and hints:
-            eng.unet.import_tuning(hints, 2 * B)
+            eng.import_tuning(hints, B)
         tuning = f"rank 0's {len(hints)} pins broadcast to all ranks"
     for i in range(warmup):
         out = one_job()

@@ -69,3 +69,31 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     const float cdf = x >= 0.f ? 1.0f - 0.5f * erfc_ax : 0.5f * erfc_ax;
     return x * cdf;
 }
+
+// The same function for a PAIR of values on the packed-fp32 pipe, without transcendentals.  The GEGLU epilogue evaluates
+// GELU 4C times per token: on the 256 x 256 tile that is 64 evaluations per lane, and gelu_erf_f's rcp + exp2 (quarter-rate
+// instructions) + 14 VALU operations made the epilogue ~10 900 cycles per workgroup, as long as 3.5 K-tiles of MFMAs
+// (profiles/r03/timelines: geglu HW=4096, epilogue 5.5 of 15.2 us).  Here
+//      x Phi(x) = x / 2 + |x| * h(min(|x|, c)),      h(a) = erf(a / sqrt 2) / 2,
+// with h a degree-12 polynomial in the centred variable t = 2 a / c - 1 (Chebyshev fit converted to monomials: coefficients
+// <= 0.5 in magnitude, so fp32 Horner loses nothing), scaled so that h(c) = 1/2 to the last bit of an fp32 Horner evaluation: for
+// x <= -c the result is 0 to within 1e-6, for x >= c it is x.  c = 4.75.  Max abs error against the erf form 6.5e-6 over all x
+// (tests/test_index_math_cpu.py evaluates THESE constants in numpy fp32), i.e. below the fp16 resolution of the output for every
+// |y| >= 0.0133 and below 1e-5 absolute elsewhere.  18 issue slots per pair (2 v_min, 13 v_pk_fma, 2 v_mul, 1 v_pk_fma).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CFGPP_GELU_C 4.75f
+#define CFGPP_GELU_POLY {4.912262559e-01f, 5.645360425e-02f, -1.591939032e-01f, 2.464362979e-01f, -1.982378513e-01f, 1.363233291e-02f, \
+                         1.386516690e-01f, -1.158297956e-01f, -9.092462249e-03f, 6.090912968e-02f, -1.936562732e-02f, -1.160200126e-02f, \
+                         6.012340542e-03f}
+__device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
+    constexpr float k[13] = CFGPP_GELU_POLY;
+    f32x2 a;
+    a.x = fminf(fabsf(x.x), CFGPP_GELU_C); a.y = fminf(fabsf(x.y), CFGPP_GELU_C);
+    const f32x2 t = __builtin_elementwise_fma(a, (f32x2){2.0f / CFGPP_GELU_C, 2.0f / CFGPP_GELU_C}, (f32x2){-1.0f, -1.0f});
+    f32x2 p = {k[12], k[12]};
+#pragma unroll
+    for (int i = 11; i >= 0; --i) p = __builtin_elementwise_fma(p, t, (f32x2){k[i], k[i]});
+    f32x2 m;
+    m.x = fabsf(x.x) * p.x; m.y = fabsf(x.y) * p.y;
+    return __builtin_elementwise_fma(x, (f32x2){0.5f, 0.5f}, m);
+}

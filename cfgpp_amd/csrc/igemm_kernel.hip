@@ -282,8 +282,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                             gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                         }
                         half4_t o;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) o[k] = (half_t)(v[k] * gelu_erf_f(gt[k]));
+                        const f32x2 g01 = gelu_erf_pk((f32x2){gt[0], gt[1]}), g23 = gelu_erf_pk((f32x2){gt[2], gt[3]});
+                        o[0] = (half_t)(v[0] * g01.x); o[1] = (half_t)(v[1] * g01.y);
+                        o[2] = (half_t)(v[2] * g23.x); o[3] = (half_t)(v[3] * g23.y);
                         *reinterpret_cast<half4_t*>(p.out + orow * p.old + f) = o;
                     }
             }
@@ -443,8 +444,9 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
                     gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                 }
                 half4_t o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = (half_t)(v[k] * gelu_erf_f(gt[k]));
+                const f32x2 g01 = gelu_erf_pk((f32x2){gt[0], gt[1]}), g23 = gelu_erf_pk((f32x2){gt[2], gt[3]});
+                o[0] = (half_t)(v[0] * g01.x); o[1] = (half_t)(v[1] * g01.y);
+                o[2] = (half_t)(v[2] * g23.x); o[3] = (half_t)(v[3] * g23.y);
                 *reinterpret_cast<half4_t*>(stg + frow * PITCH + ((j >> 1) * 32 + 8 * g + 4 * fhi) * 2) = o;
             }
 #pragma unroll
@@ -1497,8 +1499,19 @@ static unsigned long long* tl_take(int cfg, int grid, int threads, int BM, int B
     for (int i = 0; i < 12; ++i) g_tl_info[i] = info[i];
     return g_tl;
 }
-static float* g_ws = nullptr;                       // fp32 partial workspace (one device per process)
+// fp32 partial workspace of the K-split launches: ONE PER STREAM (one device per process).  Launches of one stream are
+// serialised, so they can share a buffer; an engine split into lanes (cfgpp_amd/hip_engine.py) runs forwards on several
+// streams at once, and two K-split launches in flight must not share partials.
 constexpr long WS_BYTES = 128L << 20;               // fp32 partials of one launch: T * S * BM * BN * 4 bytes must fit
+static std::map<hipStream_t, float*> g_ws_by_stream;
+static float* ws_for(hipStream_t stream) {
+    auto it = g_ws_by_stream.find(stream);
+    if (it != g_ws_by_stream.end()) return it->second;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, (size_t)WS_BYTES) != hipSuccess) p = nullptr;
+    if (p) g_ws_by_stream[stream] = p;
+    return p;
+}
 static int g_staged_epi = 1;
 extern "C" void cfgpp_igemm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 : 0; }
 static int g_big_tiles = 1;
@@ -1561,8 +1574,8 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
             if (S > 16) S = 16;
         }
         if (S >= 2 && (long)T * S * BM * BN * 4 <= WS_BYTES) {
-            if (!g_ws && hipMalloc((void**)&g_ws, (size_t)WS_BYTES) != hipSuccess) g_ws = nullptr;
-            if (g_ws) { a.n_main = 0; a.ksplit = S; a.ws = g_ws; }
+            float* const ws = ws_for(stream);
+            if (ws) { a.n_main = 0; a.ksplit = S; a.ws = ws; }
         }
     }
     const int n_tail = T - a.n_main;

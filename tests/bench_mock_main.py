@@ -27,7 +27,9 @@ def make_solver(kind, name, cfg_name, nfe, batch, device):
     def unet(z, t, ehs, te, ti):
         return pointwise_eps(z, torch.as_tensor(float(t)).reshape(1), ehs, te, ti)
     eng = MockEngine(unet, (8, 8))
-    eng.unet = types.SimpleNamespace(device_bytes=lambda: 0.0, export_tuning=lambda rows: [5, 0, 14], import_tuning=lambda h, rows: None)
+    eng.device_bytes = lambda: 0.0
+    eng.export_tuning = lambda: [5, 0, 14]
+    eng.import_tuning = lambda hints, batch: None
     eng.flops_per_forward = lambda rows: 1.0e6 * rows
     sc = types.SimpleNamespace(num_sampling=nfe)
     solver = get_solver(name, solver_config=sc, device="cpu", unet_config=TINY_SD, max_batch=batch, latent_hw=(8, 8),

@@ -6,8 +6,12 @@
   at most one conditional wrap equals the per-column ``n / part_width``, ``(n % part_width) / head_dim``,
   ``(n % part_width) % head_dim`` the epilogues used to evaluate per 16-byte piece.
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _qdiv(m, d, ulps):
@@ -87,3 +91,48 @@ def test_single_pass_layernorm_statistics_in_fp32(C):
         v = np.maximum((q * np.float32(1.0 / C) - m * m).astype(np.float32), 0)
         got = 1.0 / np.sqrt(v + np.float32(1e-5))
         assert np.max(np.abs(got - want) / want) < bound, (mu, float(np.max(np.abs(got - want) / want)))
+
+
+def test_lane_spans_partition_the_batch_without_straddling_the_halves():
+    """cfgpp_amd/hip_engine.py: lanes of the UNet batch [uc_1..uc_B, c_1..c_B] are contiguous, cover every row once and never
+    cross the null-prompt / prompt boundary (a lane's latents are one slice of z)"""
+    from cfgpp_amd.hip_engine import _lane_spans
+    for B in range(1, 18):
+        for lanes in (1, 2, 4, 6, 8, 16):
+            spans = _lane_spans(B, lanes)
+            assert spans[0][0] == 0 and spans[-1][1] == 2 * B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+            assert all(b > a for a, b in spans)
+            if lanes > 1:
+                assert all(b <= B or a >= B for a, b in spans)
+                assert len(spans) == 2 * min(lanes // 2, B)
+                sizes = [b - a for a, b in spans]
+                assert max(sizes) - min(sizes) <= 1
+
+
+def test_packed_gelu_polynomial_constants():
+    """csrc/common.h gelu_erf_pk: the shipped constants, evaluated the way the kernel evaluates them (fp32, clamp, centred
+    variable, Horner with one rounding per step), against x * Phi(x) with scipy's erf."""
+    import re
+
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "cfgpp_amd", "csrc", "common.h")).read()
+    c = np.float32(re.search(r"#define CFGPP_GELU_C ([0-9.]+)f", src).group(1))
+    body = re.search(r"#define CFGPP_GELU_POLY \{(.*?)\}", src, re.S).group(1).replace("\\", " ")
+    k = [np.float32(v.strip().rstrip("f")) for v in body.split(",")]
+    assert len(k) == 13 and max(abs(float(v)) for v in k) <= 0.5
+    x = np.concatenate([np.linspace(-12, 12, 600001), np.array([0.0, -0.0, 1e-6, -1e-6, 4.75, -4.75, 100.0, -100.0])]).astype(np.float32)
+    a = np.minimum(np.abs(x), c)
+    t = (a.astype(np.float64) * np.float64(np.float32(2.0) / c) - 1.0).astype(np.float32)       # one fma
+    p = np.full_like(t, k[12])
+    for kk in k[11::-1]:
+        p = (p.astype(np.float64) * t + np.float64(kk)).astype(np.float32)                      # fma: one rounding
+    m = np.abs(x) * p
+    y = (x.astype(np.float64) * 0.5 + m).astype(np.float32)
+    xd = x.astype(np.float64)
+    want = xd * 0.5 * (1.0 + erf(xd / np.sqrt(2.0)))
+    err = np.abs(y - want)
+    assert err.max() < 1e-5, (err.max(), x[err.argmax()])
+    assert np.abs(y[x <= -c]).max() < 2e-6 and np.abs(y[x >= c] - x[x >= c]).max() < 2e-5
+    assert y[np.abs(x) < 1e-5].max() < 1e-5
