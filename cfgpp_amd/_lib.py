@@ -37,7 +37,7 @@ class UNetConfigC(C.Structure):
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 
-# name -> (restype, argtypes); every symbol include/cfgpp.h declares
+# name -> (restype, argtypes); every symbol include/cfgpp.h declares (the drop-in boundary)
 PROTOTYPES = {
     "cfgpp_last_error": (C.c_char_p, []),
     "cfgpp_step_ddim": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
@@ -74,6 +74,10 @@ PROTOTYPES = {
     "cfgpp_text_device_bytes": (C.c_double, [_P]),
     "cfgpp_vae_encode_flops": (C.c_double, [_P, _I]),
     "cfgpp_vae_device_bytes": (C.c_double, [_P]),
+}
+
+# test hooks and development switches (cfgpp_amd/csrc/cfgpp_debug.h): same library, not part of the boundary
+DEBUG_PROTOTYPES = {
     "cfgpp_op_softmax_rows": (_I, [_P, _L, _I, _P]),
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
@@ -135,7 +139,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise CfgppError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, (res, args) in PROTOTYPES.items():
+    for name, (res, args) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError as e:

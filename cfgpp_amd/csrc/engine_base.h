@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/cfgpp.h"
+#include "cfgpp_debug.h"
 #include "igemm.h"
 
 namespace {

@@ -1728,8 +1728,9 @@ static unsigned g_tune_mask = 0xffffffffu;   // bit c: the tuner may pin tile co
 extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
 unsigned igemm_tune_mask() { return g_tune_mask; }
 
-// Arms the timeline: the `target`-th igemm_launch call from now on (0-based) records {entry, first tile landed, k-loop done,
-// stores done} per workgroup into buf[grid][8] (device memory, >= cap_blocks * 64 bytes); buf = null disarms.
+// Arms the timeline: the `target`-th igemm_launch call from now on (0-based) records 16 x uint64 per workgroup (slots: see
+// IGemmArgs::tl) into buf[grid][16] (device memory, >= cap_blocks * 128 bytes; launches with more workgroups than cap_blocks
+// are not recorded); buf = null disarms.
 extern "C" void cfgpp_igemm_timeline(void* buf, long cap_blocks, int target) {
     g_tl = (unsigned long long*)buf; g_tl_cap = buf ? cap_blocks : 0; g_tl_target = buf ? target : -1; g_tl_count = 0;
 }

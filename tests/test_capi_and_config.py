@@ -8,19 +8,32 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(path):
+    hdr = open(path).read()
+    return set(re.findall(r"\b(cfgpp_[a-z0-9_]+)\s*\(", hdr)) - {"cfgpp_unet_config"}
+
+
 def test_library_exports_every_declared_symbol():
+    """the installed header (the drop-in boundary) and the debug header (test hooks, A/B switches) are checked separately:
+    every declaration is exported and has a ctypes prototype in ITS table, and the boundary carries no hook or switch"""
     from cfgpp_amd import _lib
     from cfgpp_amd.build import build
     build(verbose=False)
     lib = _lib.load()
-    hdr = open(os.path.join(ROOT, "include", "cfgpp.h")).read()
-    declared = set(re.findall(r"\b(cfgpp_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"cfgpp_unet_config"}
-    assert declared, "no declarations parsed"
-    for name in sorted(declared):
+    public = _declared(os.path.join(ROOT, "include", "cfgpp.h"))
+    debug = _declared(os.path.join(ROOT, "cfgpp_amd", "csrc", "cfgpp_debug.h")) - {"cfgpp_last_error"}
+    assert public and debug, "no declarations parsed"
+    for name in sorted(public):
         assert hasattr(lib, name), f"{name} declared in include/cfgpp.h but not exported"
         assert name in _lib.PROTOTYPES, f"{name} has no ctypes prototype"
-    assert set(_lib.PROTOTYPES) == declared
+    for name in sorted(debug):
+        assert hasattr(lib, name), f"{name} declared in cfgpp_debug.h but not exported"
+        assert name in _lib.DEBUG_PROTOTYPES, f"{name} has no ctypes prototype"
+    assert set(_lib.PROTOTYPES) == public and set(_lib.DEBUG_PROTOTYPES) == debug
+    assert not (public & debug)
+    hooks = [n for n in public if n.startswith("cfgpp_op_") or "_set_" in n.replace("cfgpp_unet_set_context", "") or "force" in n or "timeline" in n]
+    assert hooks == [], f"test hooks / switches in the public header: {hooks}"
+    assert len(public) <= 40
     assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
 
 
