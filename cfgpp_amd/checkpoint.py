@@ -13,6 +13,10 @@ copy of such a checkpoint (no hub access here) the same components map onto this
     <dir>/text_encoder/{config.json, model.safetensors} + <dir>/tokenizer/{vocab.json, merges.txt}        -> text_encoder=
     <dir>/text_encoder_2/... + <dir>/tokenizer_2/...        (SDXL: second tower, projected pooled output, "!" padding)
 
+On a GPU device the text towers are ``text.HipClipTextTower`` - the CLIP transformer on the engine's own kernels
+(csrc/text.hip), pinned against ``transformers`` in tests/test_gpu_text.py; the torch-ops ``ClipTextTower`` is what a CPU
+device (tests only) gets.
+
 Missing pieces are left to the solver's defaults (synthetic weights / synthetic text encoder) and reported in ``missing``.
 """
 from __future__ import annotations
@@ -66,6 +70,9 @@ def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None) -
         if not ok:
             missing.append(enc)
             return None
+        if on_gpu:
+            from .text import HipClipTextTower
+            return HipClipTextTower.from_dir(e, t, device=device, **args)
         return ClipTextTower.from_dir(e, t, device=device, dtype=dtype, **args)
 
     if sdxl:

@@ -86,6 +86,15 @@ class HipEngine:
         self._pins_shared = {}        # lane row count -> True once lane 0's tile pins were handed to the other lanes
         self._ctx_key = None
         self._eps = None
+        # opt-in guard for the first runs with a real checkpoint (real SDXL activations approach the fp16 maximum in the deep
+        # blocks; the synthetic weights of the tests do not): scan eps after every forward - one host sync per step - and stop
+        # with the timestep instead of decoding a NaN image
+        self.check_finite = os.environ.get("CFGPP_CHECK_FINITE", "0") not in ("", "0")
+
+    def _finite_or_raise(self, t):
+        if not bool(torch.isfinite(self._eps).all()):
+            bad = int((~torch.isfinite(self._eps)).sum())
+            raise CfgppError(f"UNet output at t={t} holds {bad} non-finite values (fp16 overflow inside the UNet?) - CFGPP_CHECK_FINITE")
 
     # -- conditioning ------------------------------------------------------------
     def set_context(self, uc: torch.Tensor, c: torch.Tensor, text_embeds=None, time_ids=None):
@@ -138,6 +147,8 @@ class HipEngine:
         B = self.B
         if self.lanes == 1:
             eps = self.unet.forward(z, float(t), self._eps)
+            if self.check_finite:
+                self._finite_or_raise(t)
             return eps[:B], eps[B:]
         cur = torch.cuda.current_stream(self.device)
         self._ev_in.record(cur)
@@ -151,6 +162,8 @@ class HipEngine:
                 self._share_pins(r1 - r0)
             ev.record(st)
             cur.wait_event(ev)
+        if self.check_finite:
+            self._finite_or_raise(t)
         return self._eps[:B], self._eps[B:]
 
     # -- tile pins of the whole engine (bench.py: rank 0 tunes, every rank imports) ----

@@ -1,7 +1,8 @@
 """CLIP text tower on libcfgpp_hip.so (``csrc/text.hip``): same call contract as ``conditioning.ClipTextTower`` -
 ``tower(prompts, clip_skip=None) -> (hidden [n,77,D] fp16, pooled [n,P] fp16 | None)`` - without torch ops.
 
-Opt-in (``get_solver(..., text_encoder=HipClipTextTower.from_dir(...))``); the default text path is unchanged.
+What ``checkpoint.solver_kwargs_from_dir`` (``--model_dir`` of the example CLIs) builds on a GPU device; also usable directly
+(``get_solver(..., text_encoder=HipClipTextTower.from_dir(...))``).
 ``tests/test_gpu_text.py`` compares it with ``transformers.CLIPTextModel(WithProjection)`` on the same weights (CLIP-L and
 OpenCLIP-bigG widths, both activations, penultimate / clip_skip outputs, pooled projection).
 """
