@@ -183,10 +183,8 @@ def roofline_block(eng, config, B, dev, rnd):
     f1.record()
     torch.cuda.synchronize()
     forward_wall_ms = f0.elapsed_time(f1) / 10
-    # per-launch profile: ONE lane's executor alone on its stream (with lanes > 1 it holds rows / lanes of the batch; kernels of
-    # concurrent lanes share the CUs, so event brackets taken while another lane runs would time the mix, not the kernel)
-    rows = eng.unet.rows
-    z = torch.randn((min(B, rows), 4, eng.H, eng.W), device=dev)
+    rows = 2 * B
+    z = zf
     KIND = {"0": "igemm", "1": "attention", "2": "norm", "3": "small"}
     passes, flops, launches = [], {}, {}
     for t in (981.0, 501.0, 21.0):
@@ -250,7 +248,6 @@ def roofline_block(eng, config, B, dev, rnd):
            "mfma_util": None if pmc is None else {k: pmc[k].get("mfma_util") for k in ("igemm", "attention") if k in pmc},
            "achieved_per_launch_min": round(ach_min, 1),
            "launches_per_forward": ig["launches"], "avg_launch_us": round(med["igemm"] / max(ig["launches"], 1) * 1e3, 2),
-           "lanes": getattr(eng, "lanes", 1), "profiled_rows": rows,
            "unet_forward_wall_ms": round(forward_wall_ms, 3), "unet_forward_rows": 2 * B,
            "unet_forward_TFLOPs": round(eng.flops_per_forward(2 * B) / (forward_wall_ms * 1e-3) / 1e12, 1),
            "per_family_ms_per_forward": {k: round(v, 3) for k, v in med.items()},
@@ -329,7 +326,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     log(f"building engine {cfg_name} max_batch={B}")
     solver, cfg = make_solver(kind, name, cfg_name, nfe, B, dev)
     eng = solver.engine
-    log(f"engine ready, {getattr(eng, 'lanes', 1)} lane(s), device memory {eng.device_bytes() / 1e9:.2f} GB")
+    log(f"engine ready, device memory {eng.device_bytes() / 1e9:.2f} GB")
 
     one_job, total = prepare_job(solver, cfg, kind, name, B, img, lam, rank, world, dev)
     broadcast_ms = getattr(prepare_job, "broadcast_ms", 0.0)

@@ -82,10 +82,6 @@ DEBUG_PROTOTYPES = {
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
-    "cfgpp_op_ln_stats": (_I, [_P, _P, _L, _I, _F, _P]),
-    "cfgpp_op_igemm_heads_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "cfgpp_op_geglu_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
-    "cfgpp_unet_set_fuse_ln": (None, [_I]),
     "cfgpp_op_attention_prepare_vt": (_I, [_P, _I, _I, _I, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_conv_in": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -148,10 +144,6 @@ def load():
         fn.argtypes = args
     if os.environ.get("CFGPP_AUTOTUNE", "1") == "0":      # e.g. under rocprofv3 --pmc: no timing passes
         lib.cfgpp_igemm_set_autotune(0)
-    # A/B knobs of opt-in kernel variants (measurement runs; the defaults are what the library ships)
-    for env, fn in (("CFGPP_FUSE_LN", lib.cfgpp_unet_set_fuse_ln),):
-        if os.environ.get(env, "") != "":
-            fn(int(os.environ[env]))
     _lib = lib
     return lib
 

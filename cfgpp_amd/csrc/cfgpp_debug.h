@@ -22,10 +22,7 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
 /* development / A-B switch of the GroupNorm form: 0 auto, 1 always the two-launch form, 2 the one-launch
  * slab-in-registers kernel whenever the slab fits (csrc/norm_kernels.hip). */
 void cfgpp_groupnorm_set_mode(int mode);
-/* LayerNorm statistics only: stats[row] = (mean, rstd) fp32, exact two-pass variance; the projection that consumes the
- * LayerNorm applies it in its epilogue (cfgpp_op_igemm_heads_ln / cfgpp_op_geglu_ln, and the UNet's transformer blocks).
- * Both LayerNorm entry points need C % 8 == 0 and C <= 2048 (16-byte loads, the row of a wave held in registers). */
-int cfgpp_op_ln_stats(const void* x, float* stats, long rows, int C, float eps, void* stream);
+/* LayerNorm over the last axis: C % 8 == 0 and C <= 2048 (16-byte loads, the rows of a wave held in registers) */
 int cfgpp_op_layernorm(const void* x, void* y, const float* gamma, const float* beta, long rows, int C,
                        float eps, void* stream);
 /* development / A-B switch: token rows each wave of the LayerNorm kernel keeps in flight (0 = by row count, 1 / 2 / 4);
@@ -76,21 +73,6 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
-/* the head-major projection / the GEGLU projection with a LayerNorm of the input rows folded in: a = UN-normalised rows,
- * w = W * gamma (per input channel), bias = W beta (+ the layer's bias), ln_c[n] = sum_k w[n][k], ln_stats = (mean, rstd) per
- * row from cfgpp_op_ln_stats, or NULL: the kernel accumulates sum / sum of squares of its rows from the activation fragments of
- * its K loop (eps 1e-5); the epilogue forms rstd * (acc - mean * ln_c) + bias.  Same output contracts as
- * cfgpp_op_igemm_heads / cfgpp_op_igemm with epi = 1 (w and bias in the packed GEGLU order). */
-int cfgpp_op_igemm_heads_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
-                            const float* ln_c, int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width,
-                            int head_dim, int heads, int q_tok_pad, int tok_pad, void* stream);
-int cfgpp_op_geglu_ln(const void* a, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
-                      const float* ln_c, void* out, void* stream);
-/* 1: UNet engines finalized after this call fold the transformer blocks' LayerNorms into the projections that consume
- * them, (mean, rstd) per row from a statistics pass; 2: folded in, and the consuming kernel takes (mean, rstd) from its own
- * operand fragments in the K loop - no statistics launch (same function as 0, different fp16 rounding points);
- * 0 (default): separate layernorm launches */
-void cfgpp_unet_set_fuse_ln(int on);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
  * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);

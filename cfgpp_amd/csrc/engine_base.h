@@ -240,30 +240,6 @@ struct Builder {
         std::vector<half_t> r = concat_host(keys);
         return ok ? upload(r) : nullptr;
     }
-    // host copy of a 1-D fp32 parameter (LayerNorm gamma / beta that get folded into a projection)
-    std::vector<float> f32_host(const std::string& key) {
-        HostParam* p = get(key); if (!p) return {};
-        std::vector<float> v = p->f; drop(key); return v;
-    }
-    // LayerNorm folded into the projection that consumes it (IGemmArgs::ln_stats): w [N][K] (kernel row order) becomes
-    // W' = fp16(W * gamma[k]); c[n] = sum_k W'[n][k] (of the ROUNDED values the MFMAs will see); d[n] = sum_k W[n][k] * beta[k]
-    // (+ bias[n]).  Then LN(x) W^T + bias = rstd * (x W'^T - mean * c) + d.
-    static void fold_ln(std::vector<half_t>& w, long N, long K, const std::vector<float>& gamma, const std::vector<float>& beta,
-                        const std::vector<float>* bias, std::vector<float>& c, std::vector<float>& d) {
-        c.assign(N, 0.f); d.assign(N, 0.f);
-        for (long n = 0; n < N; ++n) {
-            double cs = 0.0, ds = 0.0;
-            half_t* row = &w[(size_t)n * K];
-            for (long k = 0; k < K; ++k) {
-                const float w0 = (float)row[k];
-                ds += (double)w0 * beta[k];
-                row[k] = (half_t)(w0 * gamma[k]);
-                cs += (double)(float)row[k];
-            }
-            c[n] = (float)cs;
-            d[n] = (float)(ds + (bias ? (double)(*bias)[n] : 0.0));
-        }
-    }
     // GEGLU packing: within every 64 packed rows, [0,32) value rows f, [32,64) gate rows 4C+f
     bool geglu_host(const std::string& pfx, long C, std::vector<half_t>& rw, std::vector<float>& rb) {
         HostParam* pw = get(pfx + ".weight"); HostParam* pb = get(pfx + ".bias");
@@ -290,7 +266,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // generic igemm op helpers ----------------------------------------------------
 IGemmArgs base_args() {
-    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; a.ln_eps = 1e-5f; return a;
+    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; return a;
 }
 
 struct Plan {
@@ -327,9 +303,9 @@ struct Plan {
     }
     // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
     void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
-                int tokens, int epi = EPI_STORE, const float* ln_stats = nullptr, const float* ln_c = nullptr) {
+                int tokens, int epi = EPI_STORE) {
         IGemmArgs a = base_args();
-        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias; a.ln_stats = ln_stats; a.ln_c = ln_c;
+        a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias;
         a.resid = resid; a.rmode = 0; a.rld = N; a.out = out; a.omode = 0;
         a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
         u->macs_per_row += (double)tokens * N * K;
@@ -352,11 +328,11 @@ struct Plan {
     // projection into head-major buffers
     void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
                half_t* q, half_t* k, half_t* vt, int q_tok_pad, int tok_pad, bool count = true,
-               const float* bias = nullptr, const float* ln_stats = nullptr, const float* ln_c = nullptr) {
+               const float* bias = nullptr) {
         IGemmArgs a = base_args();
         const int d = C / nheads;
         a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.epi = EPI_HEADS;
-        a.bias = bias; a.ln_stats = ln_stats; a.ln_c = ln_c;
+        a.bias = bias;
         a.rows_per_batch = tokens; a.hq = q; a.hk = k; a.hvt = vt; a.part0 = part0; a.part_width = C;
         a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
         if (count) u->macs_per_row += (double)tokens * N * K;
@@ -374,11 +350,6 @@ struct Plan {
                                       dst_padded ? 1 : 0, s);
         });
         if (ops == &u->plan) u->tag(2, 0.0, "groupnorm HW=" + std::to_string(H * W) + " C=" + std::to_string(C0 + C1));
-    }
-    // (mean, rstd) per token row for a projection with the LayerNorm folded in (IGemmArgs::ln_stats)
-    void ln_stats(const half_t* x, float* stats, int tokens, int C) {
-        ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_ln_stats(x, stats, (long)rows * tokens, C, 1e-5f, s); });
-        if (ops == &u->plan) u->tag(2, 0.0, "ln_stats HW=" + std::to_string(tokens) + " C=" + std::to_string(C));
     }
     void layernorm(const half_t* x, half_t* y, const float* g, const float* b, int tokens, int C) {
         ops->push_back([=](hipStream_t s, int rows) { return cfgpp_op_layernorm(x, y, g, b, (long)rows * tokens, C, 1e-5f, s); });

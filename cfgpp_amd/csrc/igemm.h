@@ -54,12 +54,6 @@ struct IGemmArgs {
     int walk_div;             // tiles along the minor axis of the walk (filled by igemm_launch)
     int walk_hint;            // decoded from cfg_hint by igemm_launch
     int split;                // >= 2: K-split every tile this many ways (igemm_launch's big-tile rule / diagnostics); 0: launcher's rule
-    // ---- fused LayerNorm of the A operand (EPI_HEADS / EPI_GEGLU consumers of a token-major residual stream) ----
-    // A holds the UN-normalised rows x; the weights are W' = W * gamma (per input channel), bias holds d = W beta (+ the layer's
-    // own bias); the epilogue forms rstd[m] * (acc - mean[m] * ln_c[n]) + bias[n] = (LayerNorm(x) W^T + bias)[m][n].
-    const float* ln_stats;    // [M][2] = (mean, rstd) per row (cfgpp_op_ln_stats), or null: no LayerNorm
-    const float* ln_c;        // [N] = sum_k W'[n][k] (packed order for GEGLU)
-    float ln_eps;             // epsilon of the fused LayerNorm when the kernel derives (mean, rstd) itself (ln_c set, ln_stats null)
     // ---- diagnostics (cfgpp_igemm_timeline): per-workgroup time stamps of ONE chosen launch, null otherwise ----
     int par_nb;               // time-embedding rows (batches) a tile stages in LDS (set by the launcher: covers every batch a tile's rows touch)
     unsigned long long* tl;   // [grid][16]: s_memtime at {entry, first tile landed, k-loop done, stores done}, s_memrealtime at

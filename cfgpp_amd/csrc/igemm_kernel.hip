@@ -87,56 +87,13 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
 constexpr int PAR_NB = 5;                                  // time-embedding rows (batches) of a tile when H*W >= 64 (BM <= 256): the sizes the
                                                            // occupancy figures assume; smaller feature maps take IGemmArgs::par_nb rows
 __host__ __device__ constexpr int par_bnp(int BN) { return (BN + 63) / 64 * 64; }
-__host__ __device__ constexpr int par_bytes(int BN, int nb = PAR_NB) { return par_bnp(BN) * 4 * (2 + nb); }
+__host__ __device__ constexpr int par_bytes(int BN, int nb = PAR_NB) { return par_bnp(BN) * 4 * (1 + nb); }
 struct Par {
     const char* lds;     // null: read the parameters from global memory (register-staged kernels, the K-split reduce kernel)
     int n0, b0, bnp;     // first column / first batch of the tile, padded segment length (floats)
-    const char* rows;    // fused LayerNorm: (mean, rstd) of the tile's BM rows, staged behind the column segments
-    int m0;              // first row of the tile
 };
-// LayerNorm statistics from the operand fragments the MFMAs consume anyway (LNI kernels): a lane's activation fragment is 8
-// consecutive k of ONE row, so sum and sum of squares of its row cost 8 v_dot2c_f32_f16 per fragment (fp32 accumulation),
-// no extra LDS or memory traffic and no statistics launch; the lanes that hold the other k-octets of the row are combined
-// once after the K loop.  var = E[x^2] - mean^2 in fp32 (rows of <= 1280 fp16 values: relative error ~1e-7 (1 + mean^2 / var)).
-__device__ __forceinline__ void ln_acc(const half8_t v, float& s, float& q) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 one = {(_Float16)1.f, (_Float16)1.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const h2 h = {v[2 * k], v[2 * k + 1]};
-        s = __builtin_amdgcn_fdot2(h, one, s, false);
-        q = __builtin_amdgcn_fdot2(h, h, q, false);
-    }
-    asm volatile("" : "+v"(s), "+v"(q));      // the sums are needed HERE: without it the compiler sinks a whole K-tile's accumulation behind the
-                                              // tile's last MFMA (across the DMA branches, where sched_barrier does not reach) and keeps fragment copies
-}
-__device__ __forceinline__ float2 ln_finish(float s, float q, int K, float eps) {
-    const float inv = 1.0f / (float)K;
-    const float mean = s * inv;
-    float var = q * inv - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    return make_float2(mean, rsqrtf(var + eps));
-}
-// bytes of the column segments = offset of the row segment (the launcher sizes the same way)
-__device__ __forceinline__ int par_rows_off(const IGemmArgs& p, int BN) {
-    return par_bnp(BN) * 4 * (2 + (p.par_nb > PAR_NB ? p.par_nb : PAR_NB));
-}
-// fused LayerNorm (IGemmArgs::ln_stats): (mean, rstd) of GEMM row m, or (0, 1) when the launch has none.  L: from the LDS row
-// segment (a per-row global load here sat in its own branch = one serialised memory round trip per 32-row sub-tile: the
-// +7..18 % the consumer epilogues cost in the first LayerNorm-fusion A/B, profiles/r03/ab/ln_fusion.txt)
-// `inl`: the (mean, rstd) this lane accumulated for that row in the K loop (IGemmArgs::ln_c set, ln_stats null: LNI kernels)
-template <bool L>
-__device__ __forceinline__ float2 ln_row(const IGemmArgs& p, const Par& q, int m, const float2 inl) {
-    if (p.ln_c == nullptr) return make_float2(0.f, 1.f);
-    if (p.ln_stats == nullptr) return inl;
-    if constexpr (L) return *reinterpret_cast<const float2*>(q.rows + (m - q.m0) * 8);
-    else {
-        const int mc = m < p.M ? m : p.M - 1;
-        return *reinterpret_cast<const float2*>(p.ln_stats + 2 * (long)mc);
-    }
-}
 // issue the DMA pieces (64 floats each) of the tile's parameter segments; NW = waves of the workgroup
-template <int BN, int NW, int BM>
+template <int BN, int NW>
 __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0, int m0, int wid, int lane) {
     constexpr int BNP = par_bnp(BN), NPC = BNP / 64;
     int nn = n0 + lane;                                     // + 64 * piece, clamped per piece
@@ -156,26 +113,11 @@ __device__ __forceinline__ void par_stage(const IGemmArgs& p, char* par, int n0,
         }
     };
     if (p.bias) arr(p.bias, 0);
-    if (p.ln_c) arr(p.ln_c, 1);
-    if (p.ln_stats) {
-        // (mean, rstd) of rows m0 .. m0 + BM - 1: BM * 2 floats = BM / 32 pieces
-        char* rows = par + par_rows_off(p, BN);
-        const int last = 2 * p.M - 1;
-#pragma unroll
-        for (int q = 0; q < BM / 32; ++q, ++pi) {
-            if (wid == pi % NW) {
-                int d = 2 * m0 + 64 * q + lane;
-                d = d < last ? d : last;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ln_stats + d),
-                                                 (__attribute__((address_space(3))) void*)(rows + q * 256), 4, 0, 0);
-            }
-        }
-    }
     if (p.temb) {
         for (int k = 0; k < p.par_nb; ++k) {               // (run-time count: 2 .. 5 for H*W >= 64)
             int b = b0 + k;
             b = b < nb ? b : nb - 1;
-            arr(p.temb + (long)b * p.temb_ld, 2 + k);
+            arr(p.temb + (long)b * p.temb_ld, 1 + k);
         }
     }
 }
@@ -186,34 +128,18 @@ __device__ __forceinline__ float4 par_bias4(const IGemmArgs& p, const Par& q, in
     else return *reinterpret_cast<const float4*>(p.bias + n);
 }
 template <bool L>
-__device__ __forceinline__ float4 par_lnc4(const IGemmArgs& p, const Par& q, int n) {
-    if constexpr (L) return *reinterpret_cast<const float4*>(q.lds + (q.bnp + n - q.n0) * 4);
-    else return *reinterpret_cast<const float4*>(p.ln_c + n);
-}
-template <bool L>
 __device__ __forceinline__ float4 par_temb4(const IGemmArgs& p, const Par& q, int b, int n) {
     if constexpr (L) {
         int k = b - q.b0;                              // < par_nb by the launcher's choice of par_nb
         k = k < p.par_nb ? k : p.par_nb - 1;
-        return *reinterpret_cast<const float4*>(q.lds + ((2 + k) * q.bnp + n - q.n0) * 4);
+        return *reinterpret_cast<const float4*>(q.lds + ((1 + k) * q.bnp + n - q.n0) * 4);
     } else {
         return *reinterpret_cast<const float4*>(p.temb + (long)b * p.temb_ld + n);
     }
 }
-// v[0..3] (columns n .. n+3 of a row with statistics st) <- rstd * (v - mean * c[n..])
-template <bool L>
-__device__ __forceinline__ void ln_apply4(const IGemmArgs& p, const Par& q, float (&v)[4], const float2 st, int n) {
-    if (p.ln_c != nullptr) {
-        const float4 cc = par_lnc4<L>(p, q, n);
-        v[0] = st.y * (v[0] - st.x * cc.x); v[1] = st.y * (v[1] - st.x * cc.y);
-        v[2] = st.y * (v[2] - st.x * cc.z); v[3] = st.y * (v[3] - st.x * cc.w);
-    }
-}
-
 // Shared epilogue.  lane: m = mw0 + i*32 + (lane&31);  n = nw0 + j*32 + 8*g + 4*(lane>>5) + {0..3}, g = reg>>2
 template <int MT, int NT, bool L>
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane, const Par& par,
-                                               const float2 (&lninl)[MT]) {
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane, const Par& par) {
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
 #pragma unroll
@@ -222,7 +148,6 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
         if (m >= p.M) continue;
         const int b = (HW > 0) ? qdiv(m, HW) : 0;
         const int tok = m - b * HW;
-        const float2 lnst = ln_row<L>(p, par, m, lninl[i]);
         long orow = m, rrow = m;
         if (p.omode == 1 || p.rmode == 1) {
             const long pp = padded_pix(m, HW, p.W, p.H);
@@ -273,8 +198,6 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                         float v[4], gt[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
-                        ln_apply4<L>(p, par, v, lnst, pc);
-                        ln_apply4<L>(p, par, gt, lnst, pc + 32);
                         if (p.bias) {
                             const float4 bv = par_bias4<L>(p, par, pc);
                             const float4 bg = par_bias4<L>(p, par, pc + 32);
@@ -302,7 +225,6 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
                     float v[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
-                    ln_apply4<L>(p, par, v, lnst, n);
                     if (p.bias) {
                         const float4 bb = par_bias4<L>(p, par, n);
                         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -414,8 +336,7 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
 // v * gelu(g) is staged as [32 rows][NT/2*32 features] and written as row segments (16 B per lane).
 template <int MT, int NT, bool L>
 __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
-                                                            char* stg, const Par& par,
-                                                            const float2 (&lninl)[MT]) {
+                                                            char* stg, const Par& par) {
     constexpr int WTF = (NT / 2) * 32;            // output features per wave
     constexpr int PITCH = WTF * 2 + 16;
     constexpr int CPR = WTF / 8;
@@ -425,7 +346,6 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
     const int NF = p.N >> 1;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const float2 lnst = ln_row<L>(p, par, mw0 + i * 32 + frow, lninl[i]);
 #pragma unroll
         for (int j = 0; j < NT; j += 2)
 #pragma unroll
@@ -435,8 +355,6 @@ __device__ __forceinline__ void igemm_epilogue_geglu_staged(const IGemmArgs& p, 
                 float v[4], gt[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[k] = acc[i][j][4 * g + k]; gt[k] = acc[i][j + 1][4 * g + k]; }
-                ln_apply4<L>(p, par, v, lnst, pc);
-                ln_apply4<L>(p, par, gt, lnst, pc + 32);
                 if (p.bias) {
                     const float4 bv = par_bias4<L>(p, par, pc);
                     const float4 bg = par_bias4<L>(p, par, pc + 32);
@@ -493,8 +411,7 @@ __device__ __forceinline__ void head_step(const IGemmArgs& p, const HeadCol& c, 
 // part_width % 32 == 0, head_dim % 8 == 0 (a 32-column group has one part, a 16-byte piece one head).
 template <int MT, int NT, bool L>
 __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, f32x16 (&acc)[MT][NT], int mw0, int nw0, int lane,
-                                                            char* stg /* wave-private, NT * 2560 bytes */, const Par& par,
-                                                            const float2 (&lninl)[MT]) {
+                                                            char* stg /* wave-private, NT * 2560 bytes */, const Par& par) {
     constexpr int PITCH = 80, BLK = 32 * PITCH;
     const int frow = lane & 31, fhi = lane >> 5;
     const int HW = p.rows_per_batch;
@@ -507,7 +424,6 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
         const int m0s = __builtin_amdgcn_readfirstlane(mw0 + i * 32);   // first token row of the sub-tile (multiple of 32)
         if (m0s >= p.M) continue;
         const int b = qdiv(m0s, HW), tok0 = m0s - b * HW;           // one batch, one aligned 32-token block
-        const float2 lnst = ln_row<L>(p, par, m0s + frow, lninl[i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int ng = nw0 + j * 32;                       // first column of the 32-column group
@@ -520,7 +436,6 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
                 float v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = acc[i][j][4 * g + k];
-                ln_apply4<L>(p, par, v, lnst, n);
                 if (p.bias) {
                     const float4 bb = par_bias4<L>(p, par, n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -576,12 +491,9 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged(const IGemmArgs& p, 
 // ds_write pass).  The DMA writes lane-linear (wave base + lane*16 B), so the XOR swizzle is
 // applied to the per-lane SOURCE chunk instead (same 128-B segment: coalescing unchanged).
 // AMODE (activation row map) is a template parameter: the k-loop must not branch on it.
-// LNI: the wave accumulates the LayerNorm statistics of its activation rows from the fragments of the K loop (ln_acc; launches
-// with IGemmArgs::ln_c set and ln_stats null; token-major GLDS kernels only)
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, bool LNI = false>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 __global__ void __launch_bounds__(64 * WM * WN)
 igemm_kernel(const IGemmArgs p) {
-    static_assert(!LNI || (GLDS && AMODE == 0), "inline LayerNorm statistics: LDS-DMA, token-major launches");
     constexpr int NTHR = 64 * WM * WN;
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -751,9 +663,6 @@ igemm_kernel(const IGemmArgs p) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-    float lns[MT], lnq[MT];                                // LNI: sum / sum of squares of row (lane & 31) of sub-tile i, this lane's k-octets
-#pragma unroll
-    for (int i = 0; i < MT; ++i) { lns[i] = 0.f; lnq[i] = 0.f; }
 
     // fragment read offsets: row = base + (lane&31), logical chunk = ks*2 + (lane>>5)
     const int frow = lane & 31, fhi = lane >> 5;
@@ -780,7 +689,7 @@ igemm_kernel(const IGemmArgs p) {
         // the parameter segments are the oldest loads of the kernel: covered by every counted wait.  (Requesting them AFTER the
         // prologue's tiles instead - conservative counted waits, published by the loop's draining waits - measured the same
         // in situ, profiles/r03/ab/par_late_ln_fusion_call6.txt, and the second copy of par_stage cost the 256 x 320 kernel 100 spills.)
-        if (!is_tail) par_stage<BN, WM * WN, BM>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
+        if (!is_tail) par_stage<BN, WM * WN>(p, smem + PAR_OFF, n0, m0, __builtin_amdgcn_readfirstlane(wid), lane);
 #pragma unroll
         for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(kt_begin + s_, s_);
         tl_stamp(p.tl, 9);
@@ -870,11 +779,6 @@ igemm_kernel(const IGemmArgs p) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks & 1][j], xa[ks & 1][i], acc[i][j], 0, 0, 0);
                             after_mfma();
                         }
-                        if constexpr (LNI) {      // 8 VALU instructions under the NT MFMAs just issued (pinned: left alone, the compiler
-                            __builtin_amdgcn_sched_barrier(0);      // collects a whole tile's worth behind the last MFMA and keeps fragment copies)
-                            ln_acc(xa[ks & 1][i], lns[i], lnq[i]);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
                     }
                 }
             } else {
@@ -894,11 +798,6 @@ igemm_kernel(const IGemmArgs p) {
                         for (int j = 0; j < NT; ++j) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
                             after_mfma();
-                        }
-                        if constexpr (LNI) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            ln_acc(xa[i], lns[i], lnq[i]);
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);      // keep one fragment set live: no hoisting of the next k-step's reads
@@ -1002,21 +901,8 @@ igemm_kernel(const IGemmArgs p) {
         tl_end(p.tl);
         return;
     }
-    // LNI: the two lanes of a row (k-octets of either parity) combine; every wave ends up with the statistics of exactly the
-    // rows its epilogue handles (row = lane & 31 of sub-tile i), so nothing goes through LDS
-    float2 lninl[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if constexpr (LNI) {
-            const float s2 = lns[i] + __shfl_xor(lns[i], 32), q2 = lnq[i] + __shfl_xor(lnq[i], 32);
-            lninl[i] = ln_finish(s2, q2, p.K, p.ln_eps);
-        } else {
-            lninl[i] = make_float2(0.f, 1.f);
-        }
-    }
     Par par;
     par.lds = GLDS ? smem + PAR_OFF : nullptr; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
-    par.rows = GLDS ? smem + PAR_OFF + par_rows_off(p, BN) : nullptr; par.m0 = m0;
     constexpr bool STAGED_FITS = WM * WN * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;      // (256 x 320 with 32 x 320 waves: 164 KB, no)
     if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
         // the k-loop ended with a barrier: every wave is done with the tile stages, LDS is free
@@ -1026,7 +912,7 @@ igemm_kernel(const IGemmArgs p) {
     }
     if constexpr (NT % 2 == 0) {
         if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
-            igemm_epilogue_geglu_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)), par, lninl);
+            igemm_epilogue_geglu_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)), par);
             tl_end(p.tl);
             return;
         }
@@ -1035,11 +921,11 @@ igemm_kernel(const IGemmArgs p) {
     constexpr bool HEADS_FITS = WM * WN * NT * 2560 <= NST * STAGE_BYTES && MT * NT <= 8;
     if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
         (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
-        igemm_epilogue_heads_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560), par, lninl);
+        igemm_epilogue_heads_staged<MT, NT, GLDS>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560), par);
         tl_end(p.tl);
         return;
     }
-    igemm_epilogue<MT, NT, GLDS>(p, acc, mw0, nw0, lane, par, lninl);
+    igemm_epilogue<MT, NT, GLDS>(p, acc, mw0, nw0, lane, par);
     tl_end(p.tl);
 }
 
@@ -1076,9 +962,8 @@ igemm_reduce_kernel(const IGemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] += base[sidx * sstride + (long)r * NTHR];
     }
-    Par par; par.lds = nullptr; par.n0 = 0; par.b0 = 0; par.bnp = 0; par.rows = nullptr; par.m0 = 0;      // parameters from global memory
-    const float2 noln[1] = {make_float2(0.f, 1.f)};
-    igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par, noln);
+    Par par; par.lds = nullptr; par.n0 = 0; par.b0 = 0; par.bnp = 0;      // parameters from global memory
+    igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par);
 }
 
 // ---- 128 x 160 tile as EIGHT waves of 32 x 80 on v_mfma_f32_16x16x32_f16 --------------------------------------------
@@ -1182,8 +1067,7 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
 // Needs rows_per_batch % 32 == 0, part_width % 16 == 0, head_dim % 8 == 0 (checked by mf16_supports).
 template <bool L = true>
 __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p, f32x4 (&acc)[2][5], int mw0, int nw0, int lane,
-                                                              char* stg /* wave-private, 5 * 1536 bytes */, const Par& par,
-                                                              const float2 (&lninl)[2]) {
+                                                              char* stg /* wave-private, 5 * 1536 bytes */, const Par& par) {
     constexpr int BLK = 1536, QK_PITCH = 48, VT_PITCH = 80;
     if (mw0 >= p.M) return;
     const int c16 = lane & 15, fq = lane >> 4;
@@ -1193,9 +1077,6 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     HeadCol hc[5];                                             // per 16-column group: part / head / offset of its first column
 #pragma unroll
     for (int j = 0; j < 5; ++j) hc[j] = head_col(p, nw0 + j * 16);
-    float2 lnst[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) lnst[i] = ln_row<L>(p, par, mw0 + i * 16 + c16, lninl[i]);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int ng = nw0 + j * 16;                           // first column of the 16-column group (ng < N: N % 160 == 0)
@@ -1208,7 +1089,6 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = acc[i][j][k];
-            ln_apply4<L>(p, par, v, lnst[i], n);
             if (p.bias) {
                 const float4 bb = par_bias4<L>(p, par, n);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -1250,10 +1130,9 @@ __device__ __forceinline__ void igemm_epilogue_heads_staged16(const IGemmArgs& p
     }
 }
 
-template <int AMODE, int NST, bool LNI = false>
+template <int AMODE, int NST>
 __global__ void __launch_bounds__(512)
 igemm16_kernel(const IGemmArgs p) {
-    static_assert(!LNI || AMODE == 0, "inline LayerNorm statistics: token-major launches");
     constexpr int BM = 128, BN = 160, RSTEP = 64;
     constexpr int A_CH = BM / RSTEP;                // 2 loader passes over the activation rows
     constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -1367,7 +1246,7 @@ igemm16_kernel(const IGemmArgs p) {
     const int nk = p.K >> 6;
     tl_stamp(p.tl, 8);
     constexpr int PAR_OFF = NST * STAGE_BYTES;      // epilogue parameters behind the ring
-    par_stage<BN, 8, BM>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
+    par_stage<BN, 8>(p, smem + PAR_OFF, n0, m0, wid, lane);          // oldest loads of the kernel: covered by every counted wait
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
         if (s_ < nk) {
@@ -1398,7 +1277,6 @@ igemm16_kernel(const IGemmArgs p) {
     //     during phase 1: while one wave of a SIMD sits in the memory pipe's queue the other one feeds the matrix pipe.
     //     (waves 4-7 therefore have one tile less in flight at the barrier: their counted wait is one tile shorter.)
     half8_t xa[2][2], wb[2][5];
-    float lns[2] = {0.f, 0.f}, lnq[2] = {0.f, 0.f};      // LNI: row (lane & 15) of 16-row block i, this lane's k-octets (4 s + lane >> 4)
     auto rd_frags = [&](int s, int stage) {
         const char* As = smem + stage * STAGE_BYTES;
         const char* Bs = As + BM * 128;
@@ -1437,13 +1315,6 @@ igemm16_kernel(const IGemmArgs p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if constexpr (LNI) {                                 // this phase's activation fragments, under its MFMAs
-                    if (m == 2 || m == 6) {                          // (pinned: see igemm_kernel)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (m == 2) ln_acc(xa[s][0], lns[0], lnq[0]); else ln_acc(xa[s][1], lns[1], lnq[1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
             }
         };
         phase(std::integral_constant<int, 0>{});
@@ -1472,19 +1343,7 @@ igemm16_kernel(const IGemmArgs p) {
 
     Par par;
     par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
-    par.rows = smem + PAR_OFF + par_rows_off(p, BN); par.m0 = m0;
-    float2 lninl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if constexpr (LNI) {                                         // the four lanes of a row (k-octets lane >> 4) combine
-            float s2 = lns[i] + __shfl_xor(lns[i], 16), q2 = lnq[i] + __shfl_xor(lnq[i], 16);
-            s2 += __shfl_xor(s2, 32); q2 += __shfl_xor(q2, 32);
-            lninl[i] = ln_finish(s2, q2, p.K, p.ln_eps);
-        } else {
-            lninl[i] = make_float2(0.f, 1.f);
-        }
-    }
-    if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536), par, lninl);
+    if (p.epi == EPI_HEADS) igemm_epilogue_heads_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (5 * 1536), par);
     else igemm_epilogue_staged16(p, acc, m0 + wm * 32, n0 + wn * 80, lane, smem + wid * (32 * 176), par);
     tl_end(p.tl);
 }
@@ -1500,8 +1359,8 @@ static unsigned long long* tl_take(int cfg, int grid, int threads, int BM, int B
     return g_tl;
 }
 // fp32 partial workspace of the K-split launches: ONE PER STREAM (one device per process).  Launches of one stream are
-// serialised, so they can share a buffer; an engine split into lanes (cfgpp_amd/hip_engine.py) runs forwards on several
-// streams at once, and two K-split launches in flight must not share partials.
+// serialised, so they can share a buffer; two engines driven on different streams (UNet and VAE, or two UNets) may have
+// K-split launches in flight at the same time, and those must not share partials.
 constexpr long WS_BYTES = 128L << 20;               // fp32 partials of one launch: T * S * BM * BN * 4 bytes must fit
 static std::map<hipStream_t, float*> g_ws_by_stream;
 static float* ws_for(hipStream_t stream) {
@@ -1528,24 +1387,24 @@ static int par_slots(const IGemmArgs& a, int BM) {
     return span < nbatch ? span : nbatch;
 }
 
-template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2, bool LNI = false>
+template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem_std = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) + BM * 8 : 0);      // ring + epilogue-parameter segments (columns, rows)
+    constexpr int smem_std = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN) : 0);      // ring + epilogue-parameter segments
     static_assert(smem_std <= 160 * 1024, "tile does not fit the LDS");
     constexpr int blocks_per_cu = (160 * 1024) / smem_std < 8 ? (160 * 1024) / smem_std : 8;
     constexpr int slots = 256 * blocks_per_cu;       // resident workgroups on 256 CUs
     IGemmArgs a = a_in;
     a.par_nb = par_slots(a, BM);
-    const int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) + BM * 8 : 0);
+    const int smem = NST * (BM + BN) * 128 + (GLDS ? par_bytes(BN, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) : 0);
     if (smem > 160 * 1024) {
         // feature maps under 8 x 8 with a time embedding (images under 64 px per side at the bottom level): a big tile spans more
         // batches than its LDS can stage rows for - the 64 x 64 tile (<= 66 rows of 64 floats) always fits
-        if constexpr (WM * WTM > 64 || WN * WTN > 64 || NST != 2) return launch_cfg_amode<2, 2, 32, 32, GLDS, AMODE, 2, LNI>(a_in, stream);
+        if constexpr (WM * WTM > 64 || WN * WTN > 64 || NST != 2) return launch_cfg_amode<2, 2, 32, 32, GLDS, AMODE, 2>(a_in, stream);
         else { cfgpp_set_error("igemm: %d time-embedding rows per tile do not fit the LDS", a.par_nb); return -2; }
     }
     static int attr_smem = 0;
-    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST, LNI>;
+    auto kern = igemm_kernel<WM, WN, WTM, WTN, GLDS, AMODE, NST>;
     if (smem > attr_smem) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1592,11 +1451,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int NST = 2>
 int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0:
-            if constexpr (GLDS) {      // LayerNorm folded in with the statistics taken in the K loop: the LNI instantiation
-                if (a.ln_c != nullptr && a.ln_stats == nullptr) return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST, true>(a, stream);
-            }
-            return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
+        case 0: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 0, NST>(a, stream);
         case 1: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 1, NST>(a, stream);
         case 2: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 2, NST>(a, stream);
         case 3: return launch_cfg_amode<WM, WN, WTM, WTN, GLDS, 3, NST>(a, stream);
@@ -1618,14 +1473,14 @@ static bool mf16_supports(const IGemmArgs& a) {
     return a.epi == EPI_HEADS && g_mf16_heads && a.rows_per_batch % 32 == 0 && a.M % 32 == 0 && a.part_width % 16 == 0 &&
            a.head_dim % 8 == 0;
 }
-template <int AMODE, int NST, bool LNI = false>
+template <int AMODE, int NST>
 int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.par_nb = par_slots(a, 128);
-    const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB) + 128 * 8;
-    if (smem > 160 * 1024) return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2, LNI>(a_in, stream);   // (feature maps under 8 x 8: see launch_cfg_amode)
+    const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB);
+    if (smem > 160 * 1024) return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2>(a_in, stream);   // (feature maps under 8 x 8: see launch_cfg_amode)
     static int attr_smem = 0;
-    auto kern = igemm16_kernel<AMODE, NST, LNI>;
+    auto kern = igemm16_kernel<AMODE, NST>;
     if (smem > attr_smem) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_smem = smem;
@@ -1644,9 +1499,7 @@ int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
 template <int NST>
 int launch_mf16(const IGemmArgs& a, hipStream_t stream) {
     switch (a.amode) {
-        case 0:
-            if (a.ln_c != nullptr && a.ln_stats == nullptr) return launch_mf16_amode<0, NST, true>(a, stream);
-            return launch_mf16_amode<0, NST>(a, stream);
+        case 0: return launch_mf16_amode<0, NST>(a, stream);
         case 1: return launch_mf16_amode<1, NST>(a, stream);
         case 2: return launch_mf16_amode<2, NST>(a, stream);
         case 3: return launch_mf16_amode<3, NST>(a, stream);
@@ -1751,11 +1604,6 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
     CFGPP_REQUIRE(a.rows_per_batch <= 0 || a.M / a.rows_per_batch < (1 << 20), "igemm: %d rows in batches of %d (batch index must stay below 2^20)", a.M, a.rows_per_batch);
-    CFGPP_REQUIRE(a.ln_c == nullptr || (a.epi != EPI_STORE && a.amode == 0),
-                  "igemm: the fused LayerNorm needs a token-major EPI_HEADS / EPI_GEGLU launch");
-    CFGPP_REQUIRE(a.ln_stats == nullptr || a.ln_c != nullptr, "igemm: ln_stats without ln_c");
-    CFGPP_REQUIRE(a.ln_c == nullptr || a.ln_stats != nullptr || (g_staging != 0 && a.ln_eps > 0.f),
-                  "igemm: LayerNorm statistics in the K loop need the LDS-DMA kernels and ln_eps");
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for
     // N = 64*odd (e.g. 320), 64x64 (4 waves of 32x32) for small problems.
     int cfg = g_force_cfg;

@@ -362,47 +362,6 @@ void launch_gn_slab(const GNArgs& a, int wgs, hipStream_t s) {
 // 32 waves x 640 B = 20 KB in flight, the HBM pipe wants ~64 KB per CU).  Each wave therefore loads RPW rows before it
 // reduces any of them; the per-row arithmetic (8-byte chunks lane + 64 j, butterfly sums, exact two-pass variance) is
 // the same for every RPW, so the result does not depend on it.
-// LayerNorm statistics only: (mean, rstd) per token row, fp32, exact two-pass variance over the row held in registers -
-// what layernorm_kernel computes before its affine map.  The consumer GEMM applies the normalisation in its epilogue
-// (igemm_kernel.hip: IGemmArgs::ln_stats): LN(x) W^T = rstd * (x W'^T - mean * c) + d with W' = W * gamma, c = W' 1,
-// d = W beta, so the normalised activations are never written: 2 B / element read instead of 4 B / element moved.
-template <int MAXV>
-__global__ void __launch_bounds__(256)
-ln_stats_kernel(const half_t* __restrict__ x, float2* __restrict__ stats, long rows, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int chunks = C / 8;
-    const half_t* xr = x + row * C;
-    half8_t raw[MAXV];                              // every load first (clamped chunk index), then the arithmetic
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int ch = lane + j * 64;
-        raw[j] = *reinterpret_cast<const half8_t*>(xr + (ch < chunks ? ch : chunks - 1) * 8);
-    }
-    float v[MAXV][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const bool live = lane + j * 64 < chunks;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { v[j][k] = live ? (float)raw[j][k] : 0.f; sum += v[j][k]; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const bool live = lane + j * 64 < chunks;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += live ? d * d : 0.f; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if (lane == 0) stats[row] = make_float2(mean, rsqrtf(sq / (float)C + eps));
-}
-
 template <int MAXV, int RPW>   // MAXV = max 16-byte chunks (8 channels) per lane: C <= 64 * 8 * MAXV
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
@@ -617,21 +576,6 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
     while (apb > 16 && (long)N * cdiv(HW, apb) < 1024) apb >>= 1;
     b.pix_per_block = apb;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(HW, apb), N), dim3(256), 0, s, b);
-    CFGPP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-int cfgpp_op_ln_stats(const void* x, float* stats, long rows, int C, float eps, void* stream) {
-    CFGPP_REQUIRE(C % 8 == 0 && C <= 64 * 8 * 4, "ln_stats: C=%d must be a multiple of 8 and <= 2048", C);
-    CFGPP_REQUIRE(x && stats && rows > 0, "ln_stats: bad args");
-    hipStream_t s = (hipStream_t)stream;
-    const int need = cdiv(C / 8, 64);
-#define LNS_LAUNCH(MV) hipLaunchKernelGGL((ln_stats_kernel<MV>), dim3(cdiv(rows, 4)), dim3(256), 0, s, (const half_t*)x, (float2*)stats, rows, C, eps)
-    if (need <= 1) LNS_LAUNCH(1);
-    else if (need <= 2) LNS_LAUNCH(2);
-    else if (need <= 3) LNS_LAUNCH(3);
-    else LNS_LAUNCH(4);
-#undef LNS_LAUNCH
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -31,24 +31,12 @@ struct cfgpp_unet : EngineBase {
 
     // transformer scratch (token-major)
     half_t *tok_x = nullptr, *tok_ln = nullptr, *tok_attn = nullptr, *tok_ff = nullptr;
-    float* tok_stats = nullptr;     // (mean, rstd) per token row: LayerNorms folded into the consuming projections
     // head-major Q / K / V^T scratch, ONE SET PER LEVEL: a level has fixed (heads, tokens, d), so the
     // zero padding of the head dim (d..dp) is never overwritten by a differently shaped user.
     half_t *hq[4] = {nullptr, nullptr, nullptr, nullptr}, *hk[4] = {nullptr, nullptr, nullptr, nullptr},
            *hvt[4] = {nullptr, nullptr, nullptr, nullptr};
 
 };
-
-// 1: the three LayerNorms of a transformer block are folded into the projections that consume them (QKV, cross-Q, GEGLU): a
-// statistics pass instead of a normalise-and-write pass, weights scaled by gamma, beta folded into the bias.
-// 0 (default): separate layernorm launches writing the normalised rows.  Read at finalize.
-// Measured in situ (profiles/r03/ab/ln_fusion.txt): the statistics pass is 35 % cheaper than the LayerNorm it replaces (SDXL
-// 4 rows: 2.36 -> 1.56 ms per forward), but both are latency-bound launches, and the consumers' epilogues paid the saving back
-// (+0.98 ms) - so it stays opt-in until the statistics come out of the PRODUCING GEMM's epilogue and the launches disappear.
-static int g_fuse_ln = 0;
-// 0 = LayerNorm kernels; 1 = folded into the consuming projection, (mean, rstd) from a statistics pass; 2 = folded in, the
-// consuming kernel derives (mean, rstd) from its own operand fragments in the K loop (no statistics launch at all)
-extern "C" void cfgpp_unet_set_fuse_ln(int on) { g_fuse_ln = on == 2 ? 2 : on ? 1 : 0; }
 
 namespace {
 
@@ -217,12 +205,6 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
     u->tok_ln = (half_t*)u->dmalloc((size_t)R * max_tok_c * 2);
     u->tok_attn = (half_t*)u->dmalloc((size_t)R * max_tok_c * 2);
     u->tok_ff = (half_t*)u->dmalloc((size_t)R * max_ff * 2);
-    {
-        long max_tok = 0; int H = c.sample_h, W = c.sample_w;
-        for (int i = 0; i < L; ++i) { max_tok = std::max(max_tok, (long)H * W); if (i != L - 1) { H /= 2; W /= 2; } }
-        u->tok_stats = (float*)u->dmalloc((size_t)R * max_tok * 2 * sizeof(float));
-        CFGPP_REQUIRE(u->tok_stats, "finalize: hipMalloc failed");
-    }
     u->d_gn_stats = (float*)u->dmalloc((size_t)R * (1024 * 64 * 2 + 64 * 2) * sizeof(float));
     u->d_sin_t = (float*)u->dmalloc((size_t)c0 * sizeof(float));
     u->d_emb_h = (float*)u->dmalloc((size_t)temb_dim * sizeof(float));
@@ -349,32 +331,13 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
         P.linear(u->tok_ln, C, u->tok_x, C, wpi, bpi, nullptr, tok);
         for (int k = 0; k < depth; ++k) {
             const std::string b = p + ".transformer_blocks." + std::to_string(k);
-            const bool fuse = g_fuse_ln != 0 && C % 8 == 0;
-            float *l1g = nullptr, *l1b = nullptr, *l2g = nullptr, *l2b = nullptr, *l3g = nullptr, *l3b = nullptr;
-            half_t *wqkv = nullptr, *wq2 = nullptr, *wff1 = nullptr;
-            float *bff1 = nullptr, *c1 = nullptr, *d1 = nullptr, *c2 = nullptr, *d2 = nullptr, *c3 = nullptr;
-            if (fuse) {
-                // W' = W * gamma, c = W' 1, d = W beta (+ bias): LN(x) W^T + bias = rstd * (x W'^T - mean * c) + d
-                std::vector<float> cv, dv;
-                std::vector<half_t> wh = B.concat_host({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"});
-                std::vector<float> g = B.f32_host(b + ".norm1.weight"), be = B.f32_host(b + ".norm1.bias");
-                if (B.ok) { Builder::fold_ln(wh, 3L * C, C, g, be, nullptr, cv, dv); wqkv = B.upload(wh); c1 = B.upload(cv); d1 = B.upload(dv); }
-                HostParam* pq = B.get(b + ".attn2.to_q.weight");
-                g = B.f32_host(b + ".norm2.weight"); be = B.f32_host(b + ".norm2.bias");
-                if (B.ok && pq) { wh = pq->h; B.drop(b + ".attn2.to_q.weight"); Builder::fold_ln(wh, C, C, g, be, nullptr, cv, dv); wq2 = B.upload(wh); c2 = B.upload(cv); d2 = B.upload(dv); }
-                std::vector<float> rb;
-                g = B.f32_host(b + ".norm3.weight"); be = B.f32_host(b + ".norm3.bias");
-                if (B.ok && B.geglu_host(b + ".ff.net.0.proj", C, wh, rb)) {
-                    Builder::fold_ln(wh, 8L * C, C, g, be, &rb, cv, dv); wff1 = B.upload(wh); c3 = B.upload(cv); bff1 = B.upload(dv);
-                }
-            } else {
-                l1g = B.f32(b + ".norm1.weight"); l1b = B.f32(b + ".norm1.bias");
-                l2g = B.f32(b + ".norm2.weight"); l2b = B.f32(b + ".norm2.bias");
-                l3g = B.f32(b + ".norm3.weight"); l3b = B.f32(b + ".norm3.bias");
-                wqkv = B.concat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"});
-                wq2 = B.linear(b + ".attn2.to_q.weight");
-                B.geglu(b + ".ff.net.0.proj", C, &wff1, &bff1);
-            }
+            float* l1g = B.f32(b + ".norm1.weight"); float* l1b = B.f32(b + ".norm1.bias");
+            float* l2g = B.f32(b + ".norm2.weight"); float* l2b = B.f32(b + ".norm2.bias");
+            float* l3g = B.f32(b + ".norm3.weight"); float* l3b = B.f32(b + ".norm3.bias");
+            half_t* wqkv = B.concat({b + ".attn1.to_q.weight", b + ".attn1.to_k.weight", b + ".attn1.to_v.weight"});
+            half_t* wq2 = B.linear(b + ".attn2.to_q.weight");
+            half_t* wff1 = nullptr; float* bff1 = nullptr;
+            B.geglu(b + ".ff.net.0.proj", C, &wff1, &bff1);
             half_t* wo1 = B.linear(b + ".attn1.to_out.0.weight"); float* bo1 = B.f32(b + ".attn1.to_out.0.bias");
             half_t* wkv2 = B.concat({b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"});
             half_t* wo2 = B.linear(b + ".attn2.to_out.0.weight"); float* bo2 = B.f32(b + ".attn2.to_out.0.bias");
@@ -396,24 +359,13 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             }
             ++cross_block_counter;
             // self-attention
-            float* const stats = g_fuse_ln == 2 ? nullptr : u->tok_stats;      // null: the consumer takes them in its K loop
-            if (fuse) {
-                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
-                P.heads(u->tok_x, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad, true, d1, stats, c1);
-            } else {
-                P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
-                P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
+            P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
             P.attention(HQ, HK, HVT, u->tok_attn, nheads, d, tok, tok, q_pad, k_pad);
             P.linear(u->tok_attn, C, u->tok_x, C, wo1, bo1, u->tok_x, tok);
             // cross-attention
-            if (fuse) {
-                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
-                P.heads(u->tok_x, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad, true, d2, stats, c2);
-            } else {
-                P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
-                P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
+            P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
             {
                 cfgpp_unet* uu = u;
                 u->attn_macs_per_row += 2.0 * (double)nheads * tok * 77 * d;
@@ -425,13 +377,8 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             }
             P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
             // feed-forward (GEGLU)
-            if (fuse) {
-                if (stats) P.ln_stats(u->tok_x, stats, tok, C);
-                P.linear(u->tok_x, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU, stats, c3);
-            } else {
-                P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
-                P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
+            P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);
             P.linear(u->tok_ff, 4 * C, u->tok_x, C, wff2, bff2, u->tok_x, tok);
         }
         Tensor out = u->acq(x.H, x.W, C);
@@ -637,28 +584,6 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
     a.w = (const half_t*)w; a.M = M; a.N = N; a.K = taps * (C0 + C1); a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
     a.rows_per_batch = H * W; a.resid = (const half_t*)resid; a.rmode = rmode; a.rld = rld;
     a.out = (half_t*)out; a.omode = omode; a.old = old_; a.epi = epi;
-    return igemm_launch(a, (hipStream_t)stream);
-}
-
-// the same two projections with a LayerNorm of the input rows folded in (IGemmArgs::ln_stats; w = W * gamma, bias = W beta
-// (+ bias), ln_c = row sums of w): what the transformer blocks launch for LN -> QKV / cross-Q and LN -> GEGLU
-int cfgpp_op_igemm_heads_ln(const void* a_, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
-                            const float* ln_c, int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width,
-                            int head_dim, int heads, int q_tok_pad, int tok_pad, void* stream) {
-    IGemmArgs a = base_args();
-    a.a0 = (const half_t*)a_; a.C0 = K; a.amode = 0; a.w = (const half_t*)w; a.M = M; a.N = N; a.K = K; a.bias = bias;
-    a.ln_stats = ln_stats; a.ln_c = ln_c;
-    a.epi = EPI_HEADS; a.rows_per_batch = rows_per_batch; a.hq = (half_t*)hq; a.hk = (half_t*)hk; a.hvt = (half_t*)hvt;
-    a.part0 = part0; a.part_width = part_width; a.head_dim = head_dim; a.head_dim_pad = round_up(head_dim, 32);
-    a.heads = heads; a.q_tok_pad = q_tok_pad; a.tok_pad = tok_pad;
-    return igemm_launch(a, (hipStream_t)stream);
-}
-
-int cfgpp_op_geglu_ln(const void* a_, int K, const void* w, int M, int N, const float* bias, const float* ln_stats,
-                      const float* ln_c, void* out, void* stream) {
-    IGemmArgs a = base_args();
-    a.a0 = (const half_t*)a_; a.C0 = K; a.amode = 0; a.w = (const half_t*)w; a.M = M; a.N = N; a.K = K; a.bias = bias;
-    a.ln_stats = ln_stats; a.ln_c = ln_c; a.epi = EPI_GEGLU; a.rows_per_batch = M; a.out = (half_t*)out; a.omode = 0; a.old = N / 2;
     return igemm_launch(a, (hipStream_t)stream);
 }
 

@@ -10,7 +10,7 @@ def family(k):
     if "igemm_kernel" in k or "igemm16_kernel" in k: return "igemm"          # both MFMA shapes of the implicit GEMM
     if "attn64_kernel" in k or "attn64p_kernel" in k or "xattn64_kernel" in k or "attn_kernel" in k: return "attention"
     if "gn_" in k: return "groupnorm"
-    if "layernorm" in k or "ln_stats" in k: return "layernorm"
+    if "layernorm" in k: return "layernorm"
     if "ddim_step" in k or "kdiff" in k or "lincomb" in k: return "step"
     return "other"
 

@@ -19,8 +19,6 @@ _lib.load().cfgpp_igemm_set_mf16_rounds(int(os.environ.get("MF16_ROUNDS", "2")))
 _lib.load().cfgpp_igemm_set_mf16(int(os.environ.get("MF16", "4")))                 # 3 / 4: 16x16x32-MFMA 128x160 tile by rule
 _lib.load().cfgpp_igemm_set_split_tile(int(os.environ.get("SPLIT_TILE", "14")))
 _lib.load().cfgpp_attention_set_stagger(int(os.environ.get("ATTN_STAGGER", "0")))
-if os.environ.get("FUSE_LN", "") != "":
-    _lib.load().cfgpp_unet_set_fuse_ln(int(os.environ["FUSE_LN"]))
 _lib.load().cfgpp_attention_set_cross(int(os.environ.get("ATTN_CROSS", "1")))
 _lib.load().cfgpp_attention_set_dma(int(os.environ.get("ATTN_MODE", "1")))
 _lib.load().cfgpp_igemm_set_tail_split(int(os.environ.get("TAIL_SPLIT", "1")))      # 2 = round-1 slice count (rounded up)

@@ -357,61 +357,6 @@ def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
     return out
 
 
-@case("ln_fused")
-def t_ln_fused():
-    """LayerNorm folded into the projection that consumes it (stats kernel + epilogue transform + folded weights) vs
-    fp32 torch `layer_norm(x) @ W^T`: the QKV / cross-Q head-major projections and the GEGLU projection, on every tile
-    family they can run on; rows with a mean far from zero included"""
-    out = {}
-    # statistics kernel alone
-    for C in (320, 640, 1280):
-        x = (rnd(333, C, seed=90 + C) * 2 + 1.5).half().float()
-        st = H.ln_stats(x.to(H.DEV, torch.float16)).cpu()
-        out[f"stats_mean_c{C}"] = H.err_stats(st[:, 0], x.mean(1))
-        out[f"stats_rstd_c{C}"] = H.err_stats(st[:, 1], (x.var(1, unbiased=False) + 1e-5).rsqrt())
-    # heads
-    for (B, tokens, C, nheads, cfgs) in ((2, 96, 320, 8, (0, 7, 18, 19)), (2, 160, 128, 4, (0, 1, 7, 14)),
-                                         (3, 128, 1280, 20, (0, 1, 4, 5, 6, 7, 8, 11, 12, 14, 18, 19))):
-        d = C // nheads
-        x = (rnd(B * tokens, C, seed=40) * 1.5 + rnd(B * tokens, 1, seed=41) * 3).half().float()        # per-row offsets: mean != 0
-        w = rnd(3 * C, C, scale=C ** -0.5, seed=42)
-        g, be = 1 + 0.2 * rnd(C, seed=43), 0.2 * rnd(C, seed=44)
-        y = (F.layer_norm(x, (C,), g, be, 1e-5) @ w.half().float().t()).reshape(B, tokens, 3, nheads, d)
-        wp, c, dd = H.fold_ln(w, g, be)
-        xd = x.to(H.DEV, torch.float16)
-        st = H.ln_stats(xd)
-        qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
-        for cf in cfgs:
-            H.lib().cfgpp_igemm_force_config(cf)
-            hq, hk, hvt = H.heads_project_ln(xd, wp, c, dd, st, B, tokens, C, nheads, 0, qp, kp)
-            out[f"q_c{C}_cfg{cf}"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
-            out[f"k_c{C}_cfg{cf}"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
-            out[f"vt_c{C}_cfg{cf}"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
-            # the same launch with NO statistics buffer: the kernel takes (mean, rstd) from its own fragments in the K loop
-            hq, hk, hvt = H.heads_project_ln(xd, wp, c, dd, None, B, tokens, C, nheads, 0, qp, kp)
-            out[f"q_c{C}_cfg{cf}_inline"] = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
-            out[f"k_c{C}_cfg{cf}_inline"] = H.err_stats(hk[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 1].permute(0, 2, 1, 3))
-            out[f"vt_c{C}_cfg{cf}_inline"] = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
-    # GEGLU
-    for (M, C, cfgs) in ((520, 320, (0, 1, 4, 10)), (300, 64, (0, 1)), (700, 1280, (0, 1, 4, 6, 10, 12, 14))):
-        x = (rnd(M, C, seed=50) * 1.5 + rnd(M, 1, seed=51) * 3).half().float()
-        w = rnd(8 * C, C, scale=C ** -0.5, seed=52)
-        b = rnd(8 * C, scale=0.1, seed=53)
-        g, be = 1 + 0.2 * rnd(C, seed=54), 0.2 * rnd(C, seed=55)
-        h = F.layer_norm(x, (C,), g, be, 1e-5) @ w.half().float().t() + b
-        ref = h[:, :4 * C] * F.gelu(h[:, 4 * C:])
-        wpk, bpk = H.pack_geglu(w, b)
-        wp, c, dd = H.fold_ln(wpk.float().cpu(), g, be, bpk.cpu())
-        xd = x.to(H.DEV, torch.float16)
-        st = H.ln_stats(xd)
-        for cf in cfgs:
-            H.lib().cfgpp_igemm_force_config(cf)
-            out[f"geglu_c{C}_cfg{cf}"] = H.err_stats(H.geglu_ln(xd, wp, c, dd, st), ref)
-            out[f"geglu_c{C}_cfg{cf}_inline"] = H.err_stats(H.geglu_ln(xd, wp, c, dd, None), ref)
-    H.lib().cfgpp_igemm_force_config(0)
-    return out
-
-
 @case("mf16_race")
 def t_mf16_race():
     """igemm16_kernel at full-chip grids (256 tiles, 20 .. 180 K-tiles, 3- and 4-stage rings): repeated launches must be

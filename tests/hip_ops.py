@@ -144,44 +144,6 @@ def heads_project(a, w, B, tokens, C, nheads, part0, nparts, q_pad, k_pad):
     return hq, hk, hvt
 
 
-def ln_stats(x, eps=1e-5):
-    """(mean, rstd) per row, fp32 [rows, 2] (cfgpp_op_ln_stats)"""
-    st = torch.empty((x.shape[0], 2), dtype=torch.float32, device=DEV)
-    check(lib().cfgpp_op_ln_stats(P(x), P(st), x.shape[0], x.shape[1], float(eps), stream()), "cfgpp_op_ln_stats")
-    return st
-
-
-def fold_ln(w, gamma, beta, bias=None):
-    """what the engine does at finalize for a projection that consumes a LayerNorm: W' = fp16(W * gamma), c = W' 1,
-    d = W beta (+ bias);  LN(x) W^T + bias = rstd * (x W'^T - mean * c) + d"""
-    w16 = w.half().float()
-    wp = (w16 * gamma.float()[None, :]).half()
-    c = wp.double().sum(1).float()
-    d = (w16.double() @ beta.double()).float()
-    if bias is not None:
-        d = d + bias.float()
-    return wp.to(DEV).contiguous(), c.to(DEV).contiguous(), d.to(DEV).contiguous()
-
-
-def heads_project_ln(a, wp, c, d, stats, B, tokens, C, nheads, part0, q_pad, k_pad):
-    dh = C // nheads
-    dp = round_up(dh, 32)
-    hq = torch.zeros((B * nheads, q_pad, dp), dtype=torch.float16, device=DEV)
-    hk = torch.zeros((B * nheads, k_pad, dp), dtype=torch.float16, device=DEV)
-    hvt = torch.zeros((B * nheads, dp, k_pad), dtype=torch.float16, device=DEV)
-    check(lib().cfgpp_op_attention_prepare_vt(P(hvt), B * nheads, dh, k_pad, stream()), "cfgpp_op_attention_prepare_vt")
-    check(lib().cfgpp_op_igemm_heads_ln(P(a), a.shape[1], P(wp), a.shape[0], wp.shape[0], P(d), P(stats), P(c), tokens, P(hq), P(hk),
-                                        P(hvt), part0, C, dh, nheads, q_pad, k_pad, stream()), "cfgpp_op_igemm_heads_ln")
-    return hq, hk, hvt
-
-
-def geglu_ln(a, wp, c, d, stats):
-    M, N = a.shape[0], wp.shape[0]
-    out = torch.empty((M, N // 2), dtype=torch.float16, device=DEV)
-    check(lib().cfgpp_op_geglu_ln(P(a), a.shape[1], P(wp), M, N, P(d), P(stats), P(c), P(out), stream()), "cfgpp_op_geglu_ln")
-    return out
-
-
 def vt_pos(n):
     """column of key 0..n-1 in a V^T buffer (bits 2 and 3 of the key index swapped; include/cfgpp.h)"""
     key = torch.arange(n)

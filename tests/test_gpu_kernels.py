@@ -110,11 +110,6 @@ def test_heads_projection_head_dim_40_on_the_16x16x32_tile(diag):
     _check(diag, diag.t_heads_d40, "heads_projection_d40")
 
 
-def test_layernorm_folded_into_the_consuming_projection(diag):
-    """stats kernel + epilogue transform + folded weights == layer_norm(x) @ W^T for the head-major and GEGLU projections"""
-    _check(diag, diag.t_ln_fused, "ln_fused", rel=2e-3)
-
-
 def test_16x16x32_tile_is_race_free_at_the_unet_sizes(diag):
     """the mid-tile-barrier schedule of igemm16_kernel (fragment reads a half tile ahead, staggered LDS-DMA issue) at the
     launch shapes it carries in the UNet: 12 repetitions bit-identical, and right against fp32"""

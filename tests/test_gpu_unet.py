@@ -166,3 +166,23 @@ def test_unet_output_same_with_tuning_on_and_off_including_split_launches():
     finally:
         lib.cfgpp_igemm_set_autotune(1)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_check_finite_guard_names_the_timestep(monkeypatch):
+    """CFGPP_CHECK_FINITE=1: a forward whose output is not finite stops the job with the timestep (here: an fp32 latent far
+    outside the fp16 range of conv_in's output)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from cfgpp_amd._lib import CfgppError
+    from cfgpp_amd.hip_engine import HipEngine
+    from cfgpp_amd.unet_config import TINY_SD as cfg
+    monkeypatch.setenv("CFGPP_CHECK_FINITE", "1")
+    eng = HipEngine(cfg, max_batch=1)
+    assert eng.check_finite
+    g = torch.Generator().manual_seed(0)
+    uc = (torch.randn(1, 77, cfg.cross_attention_dim, generator=g) * 0.5).half().cuda()
+    eng.set_context(uc, uc)
+    z = torch.randn(1, 4, 16, 16, generator=g).cuda()
+    eng.predict(z, 500.0)                         # finite input: passes
+    with pytest.raises(CfgppError, match="t=321"):
+        eng.predict(z * 3e38, 321.0)

@@ -71,45 +71,6 @@ def test_head_major_addressing_without_per_piece_divisions(group, head_dim):
                 assert _head_step(dd0, head0, off, head_dim) == (cn // head_dim, cn % head_dim), (ng, off)
 
 
-@pytest.mark.parametrize("C", [320, 640, 1280])
-def test_single_pass_layernorm_statistics_in_fp32(C):
-    """the LNI kernels form var = E[x^2] - mean^2 from fp32 sums of fp16 values (pairs through v_dot2c_f32_f16): rstd is good to
-    1e-4 relative for rows whose mean is up to 10 standard deviations from zero (fp16 storage noise of the GEMM it scales: 5e-4);
-    it degrades as (mean / sigma)^2 - 7e-4 at 30 sigma - which is where a per-row pivot would be needed"""
-    rng = np.random.default_rng(C)
-    for mu, bound in ((0.0, 2e-6), (3.0, 2e-5), (10.0, 1.5e-4)):
-        x = (rng.standard_normal((500, C)) + mu).astype(np.float16)
-        xd = x.astype(np.float64)
-        want = 1.0 / np.sqrt(xd.var(1) + 1e-5)
-        x32 = x.astype(np.float32)
-        s = np.zeros(500, np.float32)
-        q = np.zeros(500, np.float32)
-        for k in range(0, C, 2):                                # one dot2 per pair, fp32 accumulate
-            s = (s + (x32[:, k] + x32[:, k + 1])).astype(np.float32)
-            q = (q + (x32[:, k] * x32[:, k] + x32[:, k + 1] * x32[:, k + 1])).astype(np.float32)
-        m = (s * np.float32(1.0 / C)).astype(np.float32)
-        v = np.maximum((q * np.float32(1.0 / C) - m * m).astype(np.float32), 0)
-        got = 1.0 / np.sqrt(v + np.float32(1e-5))
-        assert np.max(np.abs(got - want) / want) < bound, (mu, float(np.max(np.abs(got - want) / want)))
-
-
-def test_lane_spans_partition_the_batch_without_straddling_the_halves():
-    """cfgpp_amd/hip_engine.py: lanes of the UNet batch [uc_1..uc_B, c_1..c_B] are contiguous, cover every row once and never
-    cross the null-prompt / prompt boundary (a lane's latents are one slice of z)"""
-    from cfgpp_amd.hip_engine import _lane_spans
-    for B in range(1, 18):
-        for lanes in (1, 2, 4, 6, 8, 16):
-            spans = _lane_spans(B, lanes)
-            assert spans[0][0] == 0 and spans[-1][1] == 2 * B
-            assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
-            assert all(b > a for a, b in spans)
-            if lanes > 1:
-                assert all(b <= B or a >= B for a, b in spans)
-                assert len(spans) == 2 * min(lanes // 2, B)
-                sizes = [b - a for a, b in spans]
-                assert max(sizes) - min(sizes) <= 1
-
-
 def test_packed_gelu_polynomial_constants():
     """csrc/common.h gelu_erf_pk: the shipped constants, evaluated the way the kernel evaluates them (fp32, clamp, centred
     variable, Horner with one rounding per step), against x * Phi(x) with scipy's erf."""
