@@ -105,6 +105,7 @@ DEBUG_PROTOTYPES = {
     "cfgpp_igemm_set_mf16": (None, [_I]),
     "cfgpp_igemm_set_mf16_rounds": (None, [_I]),
     "cfgpp_igemm_set_mf16_heads": (None, [_I]),
+    "cfgpp_igemm_set_mf16_linear": (None, [_I]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
     "cfgpp_igemm_timeline": (None, [_P, _L, _I]),

@@ -476,246 +476,6 @@ attn64_kernel(const AttnArgs a) {
     }
 }
 
-// ---- dp = 64, software-pipelined over key tiles (two score tiles live) ---------------------------------------------------------
-// PMC of attn64_kernel (d = 40, N = 4096): the matrix pipe busy 44 % and the other VALU 41 % of the SIMD cycles, both at once only
-// 19 % - a wave runs QK^T -> softmax -> PV strictly in sequence and the waves sharing a SIMD run the same phase at the same
-// time.  Here one wave keeps TWO score tiles: while the VALU works on the softmax of tile t, the matrix pipe computes
-// S(t+1) = K(t+1) Q^T; the exponentials of tile t are then issued in four groups of eight between the PV MFMAs that consume
-// the previous group.  The two pipes are independent (MI355X_MICROARCH.md), an MFMA occupies the matrix pipe for 32 cycles
-// and the wave keeps issuing VALU work behind it: the instruction ORDER below is the schedule (sched_group_barrier keeps it).
-//   * K tile t+1 must have landed one iteration earlier than in attn64_kernel: 4-stage ring (64 KB, two workgroups per CU),
-//     "tile t+1 landed" + barrier at the top of iteration t, then the DMA of tile t+3 into the stage tile t-1 has left.
-//   * a re-reference of the running maximum at tile t (rare, deferred as in attn64_kernel) also shifts S(t+1), which was
-//     accumulated on top of the OLD -m: every quantity that was formed relative to the old reference takes the same delta.
-template <int D16, bool ONES>
-__global__ void __launch_bounds__(256)
-attn64p_kernel(const AttnArgs a) {
-    constexpr int DP = 64, DT = 2, NST = 4;
-    constexpr int TILE = 64 * 128, STAGE = 2 * TILE, PPW = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    int qb, bh;
-    attn_block_map(a.nqb, qb, bh);
-    const int q0 = qb * 128 + wid * 32;
-    const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
-    const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
-    const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
-    const int r8 = lane >> 3, pc = lane & 7;
-    const half_t* ksrc[2]; const half_t* vsrc[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = wid * 16 + h * 8 + r8;
-        const int lc = pc ^ ((row >> 1) & 7);
-        ksrc[h] = Kb + (long)row * DP + lc * 8;
-        vsrc[h] = Vb + (long)row * a.k_tok_pad + lc * 8;
-    }
-    auto dma_tile = [&](int t, int stage) {
-        char* Ks = smem + stage * STAGE;
-        char* Vs = Ks + TILE;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[h] + (long)t * 64 * DP),
-                                             (__attribute__((address_space(3))) void*)(Ks + (wid * 16 + h * 8) * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[h] + (long)t * 64),
-                                             (__attribute__((address_space(3))) void*)(Vs + (wid * 16 + h * 8) * 128), 16, 0, 0);
-        }
-    };
-    const int ntiles = (a.nk_valid + 63) >> 6;
-    const int tail = a.nk_valid & 63;
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t) if (t < ntiles) dma_tile(t, t);
-    half8_t qf[D16];
-#pragma unroll
-    for (int ks = 0; ks < D16; ++ks) {
-        const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
-    }
-    f32x16 oacc[DT];
-    f32x16 negm;
-    float l_run = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    const int fsw = (l31 >> 1) & 7;
-    const int frow = l31 * 128;
-
-    // three-input maximum in ONE instruction (fmaxf on MFMA results is compiled to a canonicalising v_max plus the v_max)
-    auto max3 = [](float x, float y, float z) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; };
-    auto rd_k = [&](int t, half8_t (&kf0)[D16], half8_t (&kf1)[D16]) {
-        const char* Ks = smem + (t % NST) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < D16; ++ks) {
-            kf0[ks] = *reinterpret_cast<const half8_t*>(Ks + frow + ((((ks << 1) | hi) ^ fsw) << 4));
-            kf1[ks] = *reinterpret_cast<const half8_t*>(Ks + 32 * 128 + frow + ((((ks << 1) | hi) ^ fsw) << 4));
-        }
-    };
-    auto mask1 = [&](f32x16& v, int kbase) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (kbase + (r & 3) + 8 * (r >> 2)) < a.nk_valid ? v[r] : -INFINITY;
-    };
-    auto mask_tail = [&](int t, f32x16& s0, f32x16& s1) {
-        if (tail != 0 && t == ntiles - 1) { mask1(s0, t * 64 + 4 * hi); mask1(s1, t * 64 + 32 + 4 * hi); }
-    };
-    auto exp8 = [&](const f32x16& sv, int tt, float& psum) {
-        half8_t pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float pv = __builtin_amdgcn_exp2f(sv[8 * tt + j]);
-            if constexpr (!ONES) psum += pv;
-            pf[j] = (half_t)pv;
-        }
-        return pf;
-    };
-    // one iteration: (c0, c1) = scores of tile t (in), (n0, n1) = scores of tile t+1 (out).  The statement ORDER is the schedule
-    // (sched_barrier(0) between the groups): an MFMA is issued, then the VALU group that runs under it.
-    auto step = [&](int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
-        const bool more = t + 1 < ntiles;
-        // (a) tile t+1 has landed (this wave has issued up to tile t+NST-2: at most NST-3 younger tiles may be in flight);
-        //     barrier: every wave is past iteration t-1, so the stage of tile t-1 is free for tile t+NST-1
-        if (t + NST - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 3) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + NST - 1 < ntiles) dma_tile(t + NST - 1, (t + NST - 1) % NST);
-        // (c) S(t+1) = K(t+1) Q^T on the matrix pipe (after the last tile: tile t once more, result dropped - no branch here);
-        //     under its MFMAs: the row maximum of S(t) and, SPECULATIVELY against the current reference (right unless this tile
-        //     re-references, which is rare), the exponentials of the first 32 keys
-        half8_t kf0[D16], kf1[D16];
-        rd_k(more ? t + 1 : t, kf0, kf1);
-        const char* Vs = smem + (t % NST) * STAGE + TILE;
-        float psum = 0.f, mx = c0[0];
-        half8_t p0, p1;
-        n0 = negm; n1 = negm;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < D16; ++ks) {
-            n0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[ks], qf[ks], n0, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // VALU under this MFMA
-            if (ks == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) mx = max3(mx, c0[r], c1[r]);
-            } else if (ks == 1) {
-                p0 = exp8(c0, 0, psum);
-            } else if (ks == 3) {
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            n1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[ks], qf[ks], n1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) {
-#pragma unroll
-                for (int r = 8; r < 16; ++r) mx = max3(mx, c0[r], c1[r]);
-            } else if (ks == 1) {
-                p1 = exp8(c0, 1, psum);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("" : "+v"(p0), "+v"(p1));      // the speculative exponentials stay HERE (the compiler would sink them below the branch)
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        mask_tail(t + 1, n0, n1);                 // (wave-uniform, never taken when the key count is a multiple of 64)
-        // (d) rare after the first tile: re-reference - everything formed against the old reference takes the same delta
-        if (t == 0 || !__all(mx <= RESCALE_THR)) {
-            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { negm[r] -= delta; c0[r] -= delta; c1[r] -= delta; }
-            if (more) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { n0[r] -= delta; n1[r] -= delta; }
-            }
-            psum = 0.f;
-            p0 = exp8(c0, 0, psum);               // the speculative exponentials were against the old reference
-            p1 = exp8(c0, 1, psum);
-        }
-        // (e) O^T += V^T P^T: the exponentials of keys 32 .. 63 run under the PV MFMAs of keys 0 .. 31
-        auto pv1 = [&](const half8_t& pf, int g, int i) {
-            const int lc = (g >> 1) * 4 + 2 * (g & 1) + hi;
-            const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + i * 32 * 128 + frow + ((lc ^ fsw) << 4));
-            oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
-        };
-        half8_t p2, p3;
-        __builtin_amdgcn_sched_barrier(0);
-        pv1(p0, 0, 0); pv1(p0, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        p2 = exp8(c1, 0, psum);
-        __builtin_amdgcn_sched_barrier(0);
-        pv1(p1, 1, 0); pv1(p1, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        p3 = exp8(c1, 1, psum);
-        __builtin_amdgcn_sched_barrier(0);
-        pv1(p2, 2, 0); pv1(p2, 2, 1);
-        pv1(p3, 3, 0); pv1(p3, 3, 1);
-        if constexpr (!ONES) l_run += psum;
-    };
-    auto qk0 = [&](f32x16& s0, f32x16& s1) {
-        half8_t kf0[D16], kf1[D16];
-        rd_k(0, kf0, kf1);
-        s0 = negm; s1 = negm;
-#pragma unroll
-        for (int ks = 0; ks < D16; ++ks) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0[ks], qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[ks], qf[ks], s1, 0, 0, 0);
-        }
-    };
-
-    // prologue: S(0)
-    if (ntiles > NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PPW) : "memory");      // NST-1 tiles issued: tile 0 landed
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    f32x16 sA0, sA1, sB0, sB1;
-    qk0(sA0, sA1);
-    mask_tail(0, sA0, sA1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sB0[r] = 0.f; sB1[r] = 0.f; }
-    int t = 0;
-    for (; t + 1 < ntiles; t += 2) {
-        step(t, sA0, sA1, sB0, sB1);
-        step(t + 1, sB0, sB1, sA0, sA1);
-    }
-    if (t < ntiles) step(t, sA0, sA1, sB0, sB1);
-
-    float l_tot;
-    if constexpr (ONES) {
-        const int dr = a.d & 31;
-        float lv = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) if (dr == 8 * g) lv = oacc[DT - 1][4 * g];
-        l_tot = __shfl(lv, l31);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32);
-    }
-    const float inv_l = 1.0f / l_tot;
-    const int q = q0 + l31;
-    if (q < a.nq) {
-        const int b = bh / a.heads, head = bh - b * a.heads;
-        half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = i * 32 + 8 * g + 4 * hi;
-                if (dd < a.d) {
-                    half4_t o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[i][4 * g + k] * inv_l);
-                    *reinterpret_cast<half4_t*>(orow + dd) = o;
-                }
-            }
-    }
-}
-
 // ---- cross-attention, dp = 64, <= 128 keys (the 77 text tokens) ----------------------------------------------------------
 // With 77 keys the flash loop above is two tiles of latency per 128 queries: every workgroup loads its own copy of K / V^T
 // (32 KB) for 16 KB of Q and 16 KB of O, waits for it twice and runs the online-softmax bookkeeping for nothing
@@ -914,14 +674,15 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 2 = its software-pipelined form (two score tiles live),
-                                 // 0 = register-staged kernel (A/B switch)
+static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch).  (A software-pipelined form
+                                 // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
+                                 // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
 
-void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode; }
+void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
 
@@ -974,21 +735,6 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
         if (d16 == 3) hipLaunchKernelGGL((xattn64_kernel<3, true>), xg, dim3(256), 4 * 64 * 128, s, a, xqb, nxb);
         else if (ones) hipLaunchKernelGGL((xattn64_kernel<4, true>), xg, dim3(256), 4 * 64 * 128, s, a, xqb, nxb);
         else hipLaunchKernelGGL((xattn64_kernel<4, false>), xg, dim3(256), 4 * 64 * 128, s, a, xqb, nxb);
-        CFGPP_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    if (dt == 2 && g_attn_dma == 2) {              // dp = 64: software-pipelined kernel (two score tiles live, 4-stage ring)
-        constexpr int smem_p = 4 * 2 * 64 * 128;
-        static bool attr_p = false;
-        if (!attr_p) {
-            CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn64p_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
-            CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn64p_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
-            CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn64p_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
-            attr_p = true;
-        }
-        if (d16 == 3) hipLaunchKernelGGL((attn64p_kernel<3, true>), grid, dim3(256), smem_p, s, a);
-        else if (ones) hipLaunchKernelGGL((attn64p_kernel<4, true>), grid, dim3(256), smem_p, s, a);
-        else hipLaunchKernelGGL((attn64p_kernel<4, false>), grid, dim3(256), smem_p, s, a);
         CFGPP_HIP_CHECK(hipGetLastError());
         return 0;
     }

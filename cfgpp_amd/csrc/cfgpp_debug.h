@@ -75,6 +75,7 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
+ * 15 / 16 / 17 = 256x128 (8 waves) / 128x128 / 256x64 (4 waves) on 32-deep K-tiles, 2 - 3 workgroups per CU (token-major linears);
  * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);
  * 21..23 = register-staged 1..3 */
 void cfgpp_igemm_force_config(int cfg);
@@ -83,6 +84,8 @@ void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K 
 /* 8-wave 16x16x32-MFMA 128x160 tile for plain-store launches whose 128x160 grid is 200..256 tiles: 0 = off, 3 / 4 (default 4) =
  * on with that many LDS stages.  Rule-based (the tile sums k in a different order than the others, so the tuner never picks it). */
 void cfgpp_igemm_set_mf16(int mode);
+/* 1 (default): the rule also takes token-major linears; 0: convolutions only - the in-situ tuner then picks the linears' tile (A/B) */
+void cfgpp_igemm_set_mf16_linear(int on);
 /* 1: QKV / Q / KV projections (head-major epilogue) may use that tile too; default 0 until validated on hardware */
 void cfgpp_igemm_set_mf16_heads(int on);
 /* A/B knob of that rule: also take grids of exactly 2 .. n full rounds of 256 tiles (default 1 = one round only) */

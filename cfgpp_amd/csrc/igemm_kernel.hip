@@ -966,6 +966,174 @@ igemm_reduce_kernel(const IGemmArgs p) {
     igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par);
 }
 
+// ---- token-major linears on 32-deep K-tiles: TWO (or three) workgroups per CU -----------------------------------------------
+// The round-3 timelines of the K <= 1280 projections (QKV / Q heads, to_out, GEGLU, FF-out, proj_in / proj_out: a third of an
+// SD1.5 forward's igemm time at 290 - 620 TF/s) show what one 8-wave workgroup per CU costs them: a workgroup is prologue
+// (2 - 4 us: kernel arguments, index math, first tiles in flight) -> K loop (5 - 20 K-tiles) -> epilogue (5 - 15 us: every CU
+// bursts its stores and residual reads at the same time, 3.5 - 5.5 TB/s chip-wide), and while a CU is in the first or the last
+// phase its matrix pipe idles - half of the workgroup's life at K = 320.  The tiles above cannot share a CU: 64-deep K-tiles on
+// a 2 / 3-stage ring are 96 - 156 KB of LDS.  Here a K-tile is 32 deep: LDS rows of 64 bytes, (BM + BN) * 64 bytes per stage,
+// 72 KB for a 256 x 128 tile on a 3-stage ring -> two workgroups (16 waves, 128 VGPRs each) per CU, so one workgroup's
+// prologue / epilogue runs under the other one's MFMAs and the chip's store bursts de-synchronise.
+//   * token-major A only (amode 0: a row of A is K contiguous halfs, like a row of W): every LDS-DMA piece - 16 rows x 64 B,
+//     lane -> (row = lane >> 2, 16-byte chunk = lane & 3) - advances by the same 64 bytes per K-tile, whichever operand it
+//     belongs to; a wave's PPW pieces are precomputed (source pointer per lane, wave-uniform LDS offset).
+//   * swizzle: physical chunk = logical chunk ^ ((row >> 2) & 3), applied to the DMA's SOURCE chunk.  A fragment read (rows
+//     base + (lane & 31), logical chunk 2 * kstep + (lane >> 5)) then touches, per 16-lane group, 16 rows whose
+//     (row & 3, (row >> 2) & 3) pairs are all different: bank quad 16 * (row & 3) + 4 * (chunk ^ ((row >> 2) & 3)) - conflict free.
+//   * one barrier per K-tile (8 MFMAs per wave on the 64 x 64 wave tile); the 4 waves per SIMD of two workgroups cover it.
+//   * k is summed in the same order as igemm_kernel (16-deep MFMA steps, ascending): results are bit-identical to every other
+//     32x32x16 tile, so the in-situ tuner may pin these (configs 15 / 16 / 17).  Whole tiles only; epilogues shared.
+template <int WM, int WN, int WTM, int WTN, int NST, int WPE>
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+lin32_kernel(const IGemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * WTM, BN = WN * WTN;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int A_P = BM / 16, B_P = BN / 16;            // 16-row DMA pieces of the two operand tiles
+    constexpr int PPW = (A_P + B_P) / NW;                  // pieces per wave per K-tile
+    static_assert((A_P + B_P) % NW == 0, "pieces must divide over the waves");
+    constexpr int STAGE_BYTES = (BM + BN) * 64;
+    constexpr int PAR_OFF = NST * STAGE_BYTES;             // epilogue parameters behind the ring
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    tl_begin(p.tl);
+
+    const int bid = blockIdx.x;
+    int wg;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
+    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid - wm * WN;
+
+    // ---- loader: piece g = wid + NW * q of the K-tile; g < A_P: activation rows [16 g, 16 g + 16), else weight rows ----
+    const int prow = lane >> 2, pchunk = lane & 3;
+    const int schunk = pchunk ^ ((prow >> 2) & 3);         // the logical chunk that belongs at physical slot pchunk of that row
+    const half_t* src[PPW];
+    int dst[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int g = wid + NW * q;
+        if (g < A_P) {
+            int m = m0 + g * 16 + prow;
+            m = m < p.M ? m : p.M - 1;
+            src[q] = p.a0 + (long)m * p.K + schunk * 8;
+            dst[q] = g * 16 * 64;
+        } else {
+            int n = n0 + (g - A_P) * 16 + prow;
+            n = n < p.N ? n : p.N - 1;
+            src[q] = p.w + (long)n * p.K + schunk * 8;
+            dst[q] = BM * 64 + (g - A_P) * 16 * 64;
+        }
+    }
+    auto dma_tile = [&](int kt, int stage) {
+        char* base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + ((long)kt << 5)),
+                                             (__attribute__((address_space(3))) void*)(base + dst[q]), 16, 0, 0);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int fsw = (frow >> 2) & 3;
+    const int a_rd = (wm * WTM + frow) * 64;
+    const int b_rd = BM * 64 + (wn * WTN + frow) * 64;
+
+    const int nk = p.K >> 5;
+    tl_stamp(p.tl, 8);
+    par_stage<BN, NW>(p, smem + PAR_OFF, n0, m0, wid, lane);      // oldest loads of the kernel: covered by every counted wait
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(s_, s_);
+    tl_stamp(p.tl, 9);
+
+    auto tile_body = [&](int stage) {
+        const char* S = smem + stage * STAGE_BYTES;
+        half8_t xa[2][MT], wb[2][NT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xa[ks][i] = *reinterpret_cast<const half8_t*>(S + a_rd + i * 32 * 64 + coff);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wb[ks][j] = *reinterpret_cast<const half8_t*>(S + b_rd + j * 32 * 64 + coff);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks][j], xa[ks][i], acc[i][j], 0, 0, 0);
+    };
+    // Iteration kt: "tile kt has landed" (at most the NST-2 younger tiles' pieces outstanding) + barrier - which also says every
+    // wave is done reading tile kt-1, whose stage the DMA of tile kt+NST-1 (issued next) overwrites - then the tile's MFMAs.
+    int kt = 0, cur = 0, nxt = NST - 1;                  // stage of tile kt / of tile kt + NST - 1
+    for (; kt + NST - 1 < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt == 0) tl_stamp(p.tl, 1);
+        dma_tile(kt + NST - 1, nxt);
+        tile_body(cur);
+        if (kt == 0) tl_stamp(p.tl, 7);
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    for (; kt < nk; ++kt) {                              // no tile left to request: drain
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        tile_body(cur);
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (K < 32 * (NST - 1) never happens: K is a multiple of 64)
+    __syncthreads();                                     // every wave is done with the ring: LDS is free for the epilogue's staging
+    tl_stamp(p.tl, 2);
+
+    const int HW = p.rows_per_batch;
+    const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+    Par par;
+    par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
+    constexpr bool STAGED_FITS = NW * 32 * (WTN * 2 + 16) <= NST * STAGE_BYTES;
+    if (STAGED_FITS && p.epi == EPI_STORE && (p.N & 7) == 0 && p.staged_epi) {
+        igemm_epilogue_staged<MT, NT, true>(p, acc, mw0, nw0, lane, smem + wid * (32 * (WTN * 2 + 16)), par);
+        tl_end(p.tl);
+        return;
+    }
+    if constexpr (NT % 2 == 0) {
+        if (p.epi == EPI_GEGLU && (p.N & 127) == 0 && p.staged_epi && p.omode == 0) {
+            igemm_epilogue_geglu_staged<MT, NT, true>(p, acc, mw0, nw0, lane, smem + wid * (32 * ((NT / 2) * 64 + 16)), par);
+            tl_end(p.tl);
+            return;
+        }
+    }
+    constexpr bool HEADS_FITS = NW * NT * 2560 <= NST * STAGE_BYTES;
+    if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
+        (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
+        igemm_epilogue_heads_staged<MT, NT, true>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560), par);
+        tl_end(p.tl);
+        return;
+    }
+    igemm_epilogue<MT, NT, true>(p, acc, mw0, nw0, lane, par);
+    tl_end(p.tl);
+}
+
 // ---- 128 x 160 tile as EIGHT waves of 32 x 80 on v_mfma_f32_16x16x32_f16 --------------------------------------------
 // The in-situ A/Bs of round 2 rewarded three properties at once - 8 waves per workgroup (two per SIMD), >= 3 LDS stages
 // (two K-tiles of lookahead: inside a forward the operands come from HBM / the Infinity Cache) and one tile per CU - and no
@@ -1459,6 +1627,33 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     }
 }
 
+// token-major linears on 32-deep K-tiles (lin32_kernel): amode 0, one source, no time embedding (the transformer blocks' GEMMs)
+static bool lin32_ok(const IGemmArgs& a) { return a.amode == 0 && a.taps == 1 && a.C1 == 0 && a.temb == nullptr; }
+template <int WM, int WN, int WTM, int WTN, int NST, int WPE>
+int launch_lin32(const IGemmArgs& a_in, hipStream_t stream) {
+    constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
+    constexpr int smem = NST * (BM + BN) * 64 + par_bytes(BN, 0);
+    static_assert(smem * (WPE * 4 / (WM * WN)) <= 160 * 1024, "the workgroups that are meant to share a CU do not fit its LDS");
+    IGemmArgs a = a_in;
+    a.par_nb = 0;
+    static bool attr_set = false;
+    auto kern = lin32_kernel<WM, WN, WTM, WTN, NST, WPE>;
+    if (!attr_set) {
+        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
+    a.n_main = ntm * ntn; a.ksplit = 1; a.ws = nullptr; a.staged_epi = g_staged_epi;
+    const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * a.K;
+    a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
+    if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
+    a.walk_div = a.n_major ? ntm : ntn;
+    a.tl = tl_take(3200 + WM * 100 + WN * 10, a.n_main, NTHR, BM, BN, NST, a);
+    hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(NTHR), smem, stream, a);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
@@ -1543,6 +1738,11 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
+        // token-major linears on 32-deep K-tiles, several workgroups per CU (lin32_kernel); anything else falls back to the 64-deep
+        // tile of the same shape.  Tuner candidates (same k order as every 32x32x16 tile).
+        case 15: return lin32_ok(a) ? launch_lin32<4, 2, 64, 64, 3, 4>(a, stream) : launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128, 8 waves, 72 KB: 2 / CU
+        case 16: return lin32_ok(a) ? launch_lin32<2, 2, 64, 64, 3, 3>(a, stream) : launch_cfg<2, 2, 64, 64, true>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
+        case 17: return lin32_ok(a) ? launch_lin32<4, 1, 64, 64, 3, 2>(a, stream) : launch_cfg<4, 1, 64, 64, true>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
         // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
         // N % 160 == 0 only - anything else falls back to the 4-wave 128 x 160 tile.  Not a tuner candidate (different k order).
         case 18: return mf16_supports(a) ? launch_mf16<3>(a, stream) : launch_cfg<4, 1, 32, 160, true>(a, stream);
@@ -1564,6 +1764,8 @@ static int g_split_cfg = 14;
 extern "C" void cfgpp_igemm_set_split_tile(int cfg) { g_split_cfg = (cfg == 1 || cfg == 12) ? cfg : 14; }
 static int g_mf16 = 4;                 // 0 = off; 3 / 4 = the 8-wave 16x16x32-MFMA 128 x 160 tile (3 / 4 stages) by rule
 extern "C" void cfgpp_igemm_set_mf16(int mode) { g_mf16 = (mode == 3 || mode == 4) ? mode : 0; }
+static int g_mf16_linear = 1;          // 1: the rule also takes token-major linears (amode 0); 0: convolutions only, the tuner picks the linears' tile (A/B)
+extern "C" void cfgpp_igemm_set_mf16_linear(int on) { g_mf16_linear = on ? 1 : 0; }
 static int g_mf16_rounds = 2;          // the rule also takes grids of exactly 2 .. n full rounds of 256 tiles (1 = one round only).  Two rounds
                                        // = the M = 16384 x N = 640 class (32x32 level of SD1.5 at batch 8, 64x64 level of SDXL at batch 2): convs
                                        // 743 -> 860, 810 -> 954 TF/s in situ with the round-3 K-tile schedule (profiles/r03/ab/mf16_rounds.txt);
@@ -1646,7 +1848,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     // grid is ONE round of 200 .. 256 tiles - the M = 4096 x N = 1280 class (16x16 level of SD1.5 at batch 8, 32x32 level of
     // SDXL at batch 2).  In situ against the tuned 3-stage 256 x 128 tile: convs 762 -> 866 TF/s, FF-out K = 5120 693 -> 800,
     // to_out K = 1280 436 -> 505, SD1.5 forward 21.06 -> 20.61 ms (profiles/r02/ab/igemm_mf16_run9.txt).
-    if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a)) {
+    if (g_force_cfg == 0 && g_mf16 != 0 && g_staging != 0 && !big_split && mf16_supports(a) && (g_mf16_linear || a.amode != 0)) {
         const long t7 = (long)cdiv(a.M, 128) * (a.N / 160);
         // (also grids of exactly 2 .. g_mf16_rounds full rounds; default 2, see g_mf16_rounds)
         const bool full_rounds = t7 > 256 && t7 % 256 == 0 && t7 / 256 <= g_mf16_rounds;
@@ -1660,7 +1862,8 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const bool rule_splits = (cfg == 1 || cfg == 12 || cfg == 14) && g_tail_split && a.epi == EPI_STORE && KT >= 32 && t_rule * 2 <= (cfg == 1 ? 512 : 256);
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
-                            ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+                            ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
+                            ((h == 15 || h == 16 || h == 17) && lin32_ok(a))) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

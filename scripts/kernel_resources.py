@@ -51,5 +51,5 @@ if __name__ == "__main__":
     bad = [k for k in ks if k["spill"] not in ("0", "?") or k["scratch"] not in ("0", "?")]
     print(f"{len(ks)} kernels, {len(bad)} with spills or scratch")
     for k in (ks if "--all" in sys.argv else bad):
-        name = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k["name"]], capture_output=True, text=True).stdout.strip()
+        name = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
         print(f"  vgpr {k['vgpr']:>4} agpr {k['agpr']:>4} sgpr {k['sgpr']:>4} spill {k['spill']:>4} scratch {k['scratch']:>6} lds {k['lds']:>7}  {name[:150]}")

@@ -99,7 +99,7 @@ def t_geglu(M=260, C=64):
     ref = v * F.gelu(g)
     wp, bp = H.pack_geglu(w, b)
     out = {}
-    for c in (1, 2, 4, 6, 10, 12, 14):
+    for c in (1, 2, 4, 6, 10, 12, 14, 15, 16, 17):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
         out[f"cfg{c}"] = H.err_stats(got, ref)
@@ -196,13 +196,14 @@ def t_big():
         ak, wk = rnd(300, K, seed=88 + K), rnd(320, K, scale=K ** -0.5, seed=89 + K)
         shortk.append((K, ak, wk, ak @ wk.t()))
     # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings;
-    # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages)
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 18, 19):
+    # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages); 15 / 16 / 17: lin32_kernel (32-deep K-tiles, several
+    # workgroups per CU) for the linear - the conv falls back to the 64-deep tile of the same shape
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 15, 16, 17, 18, 19):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 14, 18, 19):
+        if c in (9, 11, 12, 14, 15, 16, 17, 18, 19):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
@@ -320,7 +321,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
     out = {}
-    for c in (0, 7, 9, 11, 12, 14):          # heuristic tile, 128x160 and the 3- / 4-stage ring tiles (LDS-staged heads epilogue)
+    for c in (0, 7, 9, 11, 12, 14, 15, 16, 17):          # heuristic tile, 128x160, the 3- / 4-stage ring tiles, the 32-deep-K-tile linears (LDS-staged heads epilogue)
         H.lib().cfgpp_igemm_force_config(c)
         hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
         sfx = "" if c == 0 else f"_cfg{c}"
@@ -341,7 +342,7 @@ def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
     d = C // nheads
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
-    cfgs = [0, 7, 18, 19]
+    cfgs = [0, 7, 15, 16, 17, 18, 19]
     out = {}
     H.lib().cfgpp_igemm_set_mf16_heads(1 if 18 in cfgs else 0)
     try:
@@ -383,6 +384,40 @@ def t_mf16_race():
                 else:
                     runs.append(H.linear(ad, wd, None, resid=rd).float().cpu())
             out[f"{name}_cfg{c}"] = dict(H.err_stats(runs[0], ref), identical_runs=all(torch.equal(runs[0], r_) for r_ in runs[1:]))
+    H.lib().cfgpp_igemm_force_config(0)
+    return out
+
+
+@case("lin32_unet_sizes")
+def t_lin32():
+    """lin32_kernel (configs 15 / 16 / 17) at the launch shapes it is meant for - to_out + residual in place (N = 320, K = 320 and
+    N = 1280, K = 1280), FF-out (K = 4 C), GEGLU, a ragged M - many workgroups per CU, full-chip grids: right against fp32,
+    BIT-IDENTICAL to the 128 x 128 tile of igemm_kernel (same k order: what lets the tuner pin them) and identical run to run"""
+    out = {}
+    shapes = (("to_out_c320", 16384, 320, 320, True, 0), ("to_out_c1280", 4096, 1280, 1280, True, 0), ("ff_out_c320", 8192, 320, 1280, True, 0),
+              ("ragged", 1000, 192, 448, False, 0), ("geglu_c320", 8192, 2560, 320, False, 1))
+    for name, M, N, K, resid, epi in shapes:
+        a = rnd(M, K, seed=len(name))
+        w = rnd(N, K, scale=K ** -0.5, seed=len(name) + 1)
+        b = rnd(N, scale=0.1, seed=len(name) + 2)
+        r = rnd(M, N, seed=len(name) + 3) if resid else None
+        ad, bd = a.to(H.DEV, torch.float16), b.to(H.DEV)
+        rd = r.to(H.DEV, torch.float16) if resid else None
+        if epi == 1:
+            h = a @ w.t() + b
+            v, g = h.chunk(2, dim=-1)
+            ref = v * F.gelu(g)
+            wd, bd = H.pack_geglu(w, b)
+        else:
+            ref = a @ w.t() + b + (r if resid else 0)
+            wd = w.to(H.DEV, torch.float16)
+        H.lib().cfgpp_igemm_force_config(1)
+        base = H.linear(ad, wd, bd, rd, epi=epi)
+        for c in (15, 16, 17):
+            H.lib().cfgpp_igemm_force_config(c)
+            got = H.linear(ad, wd, bd, rd, epi=epi)
+            same = all(torch.equal(got, H.linear(ad, wd, bd, rd, epi=epi)) for _ in range(6))
+            out[f"{name}_cfg{c}"] = dict(H.err_stats(got, ref), identical_runs=bool(same), equals_cfg1=bool(torch.equal(got, base)))
     H.lib().cfgpp_igemm_force_config(0)
     return out
 
