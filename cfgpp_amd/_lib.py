@@ -88,6 +88,7 @@ DEBUG_PROTOTYPES = {
     "cfgpp_op_vae_posterior": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "cfgpp_op_conv_out": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_conv_out_ex": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P]),
+    "cfgpp_conv_out_set_tiled": (None, [_I]),
     "cfgpp_op_sinusoid": (_I, [_P, _F, _P, _I, _I, _I, _I, _P]),
     "cfgpp_op_skinny_gemm": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_op_f16_to_f32_rows": (_I, [_P, _P, _I, _I, _I, _I, _P]),

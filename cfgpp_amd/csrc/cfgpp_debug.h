@@ -54,6 +54,8 @@ int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, 
  * decoder's conv_out with the sampler's `(img / 2 + 0.5).clamp(0, 1)` folded in) */
 int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                          int R, int H, int W, int C, int Cout, float post_scale, float post_shift, int clamp01, void* stream);
+/* A/B switch: 1 (default) conv_out on maps of >= 128 x 128 pixels runs the LDS-tiled kernel, 0 the wave-per-pixel kernel */
+void cfgpp_conv_out_set_tiled(int on);
 int cfgpp_op_sinusoid(const float* vals, float scalar, float* out, int count, int dim, int out_ld, int out_off,
                       void* stream);
 int cfgpp_op_skinny_gemm(const float* x, int ldx, const void* w, const float* bias, const float* addend, int add_ld,

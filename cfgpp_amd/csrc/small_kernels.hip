@@ -119,6 +119,77 @@ conv_out_kernel(const half_t* __restrict__ x, TOUT* __restrict__ out, const half
 }
 
 // ---------------------------------------------------------------------------
+// conv_out on large maps (the VAE decoder's last conv: 128 channels -> 3 at 512^2 / 1024^2): the wave-per-pixel kernel
+// above costs 1.6 ms per 8 x 512^2 images against a 0.15 ms read-once floor (profiles/r03/vae_b8_64.txt): 2 M waves, each
+// with 2.25 exposed load round trips, a 6-step shuffle reduction per output and three scattered 4-byte stores.  Here a
+// workgroup owns an 8 x 32 pixel tile (thread = pixel): per 64-channel block the 10 x 34 halo tile goes HBM -> LDS once
+// (coalesced 128-byte pixel rows; 144-byte LDS pitch: the 16 lanes of a ds_read_b128 group - consecutive pixels - fall on
+// 36 i mod 64, sixteen different bank quads), every thread walks its 9 taps x 8 chunks out of LDS, the weights are wave-uniform
+// and come through the scalar cache, two MACs per v_dot2_f32_f16, and a wave stores 2 x 128 contiguous bytes per output plane.
+// ---------------------------------------------------------------------------
+template <int CO, typename TOUT>
+__global__ void __launch_bounds__(256)
+conv_out_tile_kernel(const half_t* __restrict__ x, TOUT* __restrict__ out, const half_t* __restrict__ w,
+                     const float* __restrict__ bias, int R, int H, int W, int C, int cout_real,
+                     float post_scale, float post_shift, int clamp01) {
+    constexpr int TH = 8, TW = 32, HH = TH + 2, HW_ = TW + 2, PITCH = 144;
+    __shared__ __attribute__((aligned(16))) char tile[HH * HW_ * PITCH];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int txi = b % tiles_x; b /= tiles_x;
+    const int tyi = b % tiles_y; const int r = b / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;                  // first output pixel of the tile = halo-tile origin in PADDED coordinates
+    const int ty = tid >> 5, tx = tid & 31;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    const half_t* xr = x + (long)r * (H + 2) * (W + 2) * C;
+    for (int cb = 0; cb < C; cb += 64) {
+        __syncthreads();                                     // the previous block's reads are done
+        // halo tile: HH x HW_ pixels x 8 chunks of 16 bytes; padded coordinates (y0 + hy, x0 + hx) exist for hy <= H + 1 - y0, ...
+        for (int i = tid; i < HH * HW_ * 8; i += 256) {
+            const int px = i >> 3, ch = i & 7;
+            const int hy = px / HW_, hx = px - hy * HW_;
+            const int gy = y0 + hy, gx = x0 + hx;
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gy < H + 2 && gx < W + 2) v = *reinterpret_cast<const half8_t*>(xr + ((long)gy * (W + 2) + gx) * C + cb + ch * 8);
+            *reinterpret_cast<half8_t*>(tile + px * PITCH + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * (tap / 3);
+            const char* px = tile + ((ty + dy) * HW_ + tx + dx) * PITCH;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const half8_t xv = *reinterpret_cast<const half8_t*>(px + ch * 16);
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const half8_t wv = *reinterpret_cast<const half8_t*>(w + ((long)o * 9 + tap) * C + cb + ch * 8);      // wave-uniform: scalar loads
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[o] = __builtin_amdgcn_fdot2((h2){xv[2 * k], xv[2 * k + 1]}, (h2){wv[2 * k], wv[2 * k + 1]}, acc[o], false);
+                }
+            }
+        }
+    }
+    const int y = y0 + ty, xq = x0 + tx;
+    if (y < H && xq < W) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            if (o < cout_real) {
+                float v = acc[o] + (bias ? bias[o] : 0.f);
+                v = v * post_scale + post_shift;
+                if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                out[((long)(r * cout_real + o) * H + y) * W + xq] = (TOUT)v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos=True,
 // downscale_freq_shift=0): out[i][0:half] = cos(v_i * e_j), out[i][half:] = sin(v_i * e_j),
 // e_j = exp(-ln(10000) * j / half).  Values are rounded through fp16 like the
@@ -281,6 +352,8 @@ int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, co
 
 int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                          int R, int H, int W, int C, int Cout, float post_scale, float post_shift, int clamp01, void* stream);
+static int g_conv_out_tiled = 1;      // A/B switch: 0 = always the wave-per-pixel kernel
+void cfgpp_conv_out_set_tiled(int on) { g_conv_out_tiled = on ? 1 : 0; }
 
 int cfgpp_op_conv_out(const void* x, void* out, int out_is_half, const void* w, const float* bias,
                       int R, int H, int W, int C, int Cout, void* stream) {
@@ -297,6 +370,17 @@ int cfgpp_op_conv_out_ex(const void* x, void* out, int out_is_half, const void* 
     const long total = (long)R * H * W;
     dim3 grid(cdiv(total, 4));
     hipStream_t s = (hipStream_t)stream;
+    if (Cout <= 4 && C % 64 == 0 && (long)H * W >= 128 * 128 && g_conv_out_tiled) {      // large maps (VAE decoder): the LDS-tiled kernel
+        dim3 tg((unsigned)((long)R * cdiv(H, 8) * cdiv(W, 32)));
+        if (out_is_half)
+            hipLaunchKernelGGL((conv_out_tile_kernel<4, half_t>), tg, dim3(256), 0, s, (const half_t*)x, (half_t*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
+        else if (Cout <= 3)
+            hipLaunchKernelGGL((conv_out_tile_kernel<3, float>), tg, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
+        else
+            hipLaunchKernelGGL((conv_out_tile_kernel<4, float>), tg, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);
+        CFGPP_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (Cout > 4) {       // VAE encoder moments (8 channels); weights must hold 8 output rows
         CFGPP_REQUIRE(!out_is_half, "conv_out: 8-channel output is fp32 only");
         hipLaunchKernelGGL((conv_out_kernel<8, float>), grid, dim3(256), 0, s, (const half_t*)x, (float*)out, (const half_t*)w, bias, R, H, W, C, Cout, post_scale, post_shift, clamp01);

@@ -438,6 +438,20 @@ def t_cio():
     b2 = rnd(4, scale=0.1, seed=43)
     ref2 = F.conv2d(x, w2, b2, padding=1)
     out["conv_out"] = H.err_stats(H.conv_out(H.to_pn(x), w2, b2.to(H.DEV)), ref2)
+    # maps of >= 128 x 128 pixels take the LDS-tiled kernel: sizes that are not multiples of the 8 x 32 tile, 3 and 4 outputs,
+    # fp32 and fp16 results, two 64-channel blocks; and the same launch through the wave-per-pixel kernel (A/B switch)
+    for (R, C, Hh, Ww, Co, half) in ((2, 128, 136, 152, 3, False), (1, 64, 128, 128, 4, True), (1, 128, 130, 161, 4, False)):
+        xb = rnd(R, C, Hh, Ww, seed=44 + Co)
+        wb = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=45)
+        bb = rnd(Co, scale=0.1, seed=46)
+        refb = F.conv2d(xb.half().float(), wb.half().float(), bb, padding=1)
+        xpn = H.to_pn(xb)
+        got = H.conv_out(xpn, wb, bb.to(H.DEV), out_half=half)
+        out[f"conv_out_tiled_{Hh}x{Ww}_c{C}_o{Co}"] = H.err_stats(got, refb)
+        H.lib().cfgpp_conv_out_set_tiled(0)
+        old_k = H.conv_out(xpn, wb, bb.to(H.DEV), out_half=half)
+        H.lib().cfgpp_conv_out_set_tiled(1)
+        out[f"conv_out_tiled_vs_wave_{Hh}x{Ww}_o{Co}"] = H.err_stats(got, old_k.float().cpu())
     return out
 
 
