@@ -97,3 +97,39 @@ __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
     m.x = fabsf(x.x) * p.x; m.y = fabsf(x.y) * p.y;
     return __builtin_elementwise_fma(x, (f32x2){0.5f, 0.5f}, m);
 }
+
+// ---- LayerNorm of ONE row held by a wave (shared by layernorm_kernel and the row-block loader of rb_kernel, so that both
+// produce the same bits): lane l holds the 16-byte chunks l, l + 64, ... (8 channels each) of the row; exact two-pass variance.
+template <int MAXV>
+__device__ __forceinline__ void ln_row_stats(const half8_t (&raw)[MAXV], int chunks, int C, float eps, int lane,
+                                             float (&v)[MAXV][8], float& mean, float& rstd) {
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const bool live = lane + j * 64 < chunks;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[j][k] = live ? (float)raw[j][k] : 0.f; sum += v[j][k]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const bool live = lane + j * 64 < chunks;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[j][k] - mean; sq += live ? d * d : 0.f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    rstd = rsqrtf(sq / (float)C + eps);
+}
+// chunk j of the normalised row: (v - mean) * rstd * gamma + beta, rounded to fp16
+__device__ __forceinline__ half8_t ln_row_affine(const float (&v)[8], float mean, float rstd, const float4 (&g)[2], const float4 (&be)[2]) {
+    const float gg[8] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w};
+    const float bb[8] = {be[0].x, be[0].y, be[0].z, be[0].w, be[1].x, be[1].y, be[1].z, be[1].w};
+    half8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (half_t)((v[k] - mean) * rstd * gg[k] + bb[k]);
+    return o;
+}

@@ -385,34 +385,9 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const flo
         }
     }
     float v[RPW][MAXV][8];
-    float sum[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        sum[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const bool live = lane + j * 64 < chunks;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { v[r][j][k] = live ? (float)raw[r][j][k] : 0.f; sum[r] += v[r][j][k]; }
-        }
-    }
     float mean[RPW], rstd[RPW];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum[r] += __shfl_xor(sum[r], o);
-        mean[r] = sum[r] / (float)C;
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const bool live = lane + j * 64 < chunks;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const float d = v[r][j][k] - mean[r]; sq += live ? d * d : 0.f; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-        rstd[r] = rsqrtf(sq / (float)C + eps);
-    }
+    for (int r = 0; r < RPW; ++r) ln_row_stats<MAXV>(raw[r], chunks, C, eps, lane, v[r], mean[r], rstd[r]);      // (common.h)
     // gamma / beta of this lane's chunks: again every load first
     float4 g[MAXV][2], be[MAXV][2];
 #pragma unroll
@@ -426,17 +401,9 @@ layernorm_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const flo
     for (int j = 0; j < MAXV; ++j) {
         const int ch = lane + j * 64;
         if (ch < chunks) {
-            const float gg[8] = {g[j][0].x, g[j][0].y, g[j][0].z, g[j][0].w, g[j][1].x, g[j][1].y, g[j][1].z, g[j][1].w};
-            const float bb[8] = {be[j][0].x, be[j][0].y, be[j][0].z, be[j][0].w, be[j][1].x, be[j][1].y, be[j][1].z, be[j][1].w};
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                if (row0 + r < rows) {
-                    half8_t o;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) o[k] = (half_t)((v[r][j][k] - mean[r]) * rstd[r] * gg[k] + bb[k]);
-                    *reinterpret_cast<half8_t*>(y + (row0 + r) * C + ch * 8) = o;
-                }
-            }
+            for (int r = 0; r < RPW; ++r)
+                if (row0 + r < rows) *reinterpret_cast<half8_t*>(y + (row0 + r) * C + ch * 8) = ln_row_affine(v[r][j], mean[r], rstd[r], g[j], be[j]);
         }
     }
 }
