@@ -157,7 +157,7 @@ def cpu_baseline(cfg_name, name, nfe, lam, img, limit_s=240):
     return json.loads(lines[-1])
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def roofline_block(eng, config, B, dev, rnd):

@@ -10,7 +10,14 @@ from cfgpp_amd import _lib
 from cfgpp_amd.hip_engine import HipEngine
 hf = os.path.join(ROOT, "gpurun_out", f"tune_{a.cfg}_rows{a.rows}.json")
 if a.load_hints: _lib.load().cfgpp_igemm_set_autotune(1)
-eng = HipEngine(a.cfg, max_batch=a.rows // 2)
+# the synthetic state dict is generated once per box and cached (SDXL: ~45 s of CPU RNG per process otherwise; five processes per config)
+from cfgpp_amd.unet_config import CONFIGS
+from cfgpp_amd.weights import synth_state_dict
+cache = f"/tmp/cfgpp_synth_{a.cfg}.safetensors"
+if not os.path.exists(cache):
+    from safetensors.torch import save_file
+    save_file({k: v.half().contiguous() for k, v in synth_state_dict(CONFIGS[a.cfg], 0).items()}, cache + ".tmp"); os.replace(cache + ".tmp", cache)
+eng = HipEngine(a.cfg, max_batch=a.rows // 2, weights=cache)
 cfg = eng.cfg; B = a.rows // 2
 g = torch.Generator().manual_seed(0)
 uc = torch.randn(1, 77, cfg.cross_attention_dim, generator=g).half() * 0.5; c = torch.randn(B, 77, cfg.cross_attention_dim, generator=g).half() * 0.5

@@ -75,3 +75,54 @@ def test_vt_key_permutation():
             keys = [16 * tt + 8 * b + 4 * hi + r for b in range(2) for r in range(4)]
             p = sorted(pos(k) for k in keys)
             assert p == list(range(p[0], p[0] + 8)) and p[0] % 8 == 0, (tt, hi, p)
+
+
+# ---- round 4: 64-byte rows (32-deep K-tiles of lin32_kernel / rb_kernel), padded row blocks, the conv_out halo tile ----
+def test_64_byte_rows_fragment_reads_and_dma_swizzle():
+    """lin32_kernel / the weight rings of rb_kernel: rows of 64 bytes (4 chunks), physical = logical ^ ((row >> 2) & 3); a
+    fragment read is row = base + (lane & 31), logical chunk 2 * ks + (lane >> 5), ks = 0, 1; the DMA piece is 16 rows, lane ->
+    (row = lane >> 2, physical slot = lane & 3) loading source chunk slot ^ ((row >> 2) & 3)"""
+    for base in range(0, 384, 32):
+        for ks in range(2):
+            def addr(l, base=base, ks=ks):
+                row = base + (l & 31)
+                return row * 64 + (((2 * ks + (l >> 5)) ^ ((row >> 2) & 3)) << 4)
+            assert _conflict_free(addr), (base, ks)
+    for piece in range(24):
+        for lane in range(64):
+            r = piece * 16 + (lane >> 2)
+            src_chunk = (lane & 3) ^ (((lane >> 2) >> 2) & 3)          # what the kernel computes from the lane alone
+            assert src_chunk == (lane & 3) ^ ((r >> 2) & 3)           # = the swizzle of the tile row the piece lands on
+            assert (src_chunk ^ ((r >> 2) & 3)) == (lane & 3)         # a read of logical `src_chunk` at row r finds slot lane & 3
+
+    def unswizzled(l):
+        return (l & 31) * 64 + ((l >> 5) << 4)
+    assert max(max(q.count(v) for v in set(q)) for q in _quads(unswizzled)) >= 4
+
+
+def test_row_block_pitch_makes_fragment_reads_conflict_free():
+    """rb_kernel's resident A block: [rows][2 C + 16] bytes, fragment read row = 32 i + (lane & 31), 16-byte chunk = 4 kt + 2 ks +
+    (lane >> 5).  The 16-byte pad turns the pitch into 36 (C = 320) / 4 (C = 640) dwords mod 64; without it (pitch 640 / 1280
+    bytes) the 16 rows of a lane group fall on 2 / 1 bank quads."""
+    for C in (64, 128, 192, 256, 320, 384, 448, 512, 576, 640):
+        pitch = 2 * C + 16
+        for chunk in range(0, C // 8, 2):
+            def addr(l, pitch=pitch, chunk=chunk):
+                return (l & 31) * pitch + (chunk + (l >> 5)) * 16
+            assert _conflict_free(addr), (C, chunk)
+    for C in (320, 640):
+        def bare(l, C=C):
+            return (l & 31) * 2 * C + ((l >> 5) << 4)
+        assert max(max(q.count(v) for v in set(q)) for q in _quads(bare)) >= 8
+
+
+def test_conv_out_halo_tile_reads_are_conflict_free():
+    """conv_out_tile_kernel: thread (ty, tx) = pixel of an 8 x 32 tile reads 16-byte chunk ch of halo pixel (ty + dy, tx + dx) from
+    a [10 x 34 pixels][144 bytes] tile; a wave = two tile rows"""
+    for dy in range(3):
+        for dx in range(3):
+            for ch in range(8):
+                def addr(l, dy=dy, dx=dx, ch=ch):
+                    ty, tx = l >> 5, l & 31
+                    return ((ty + dy) * 34 + tx + dx) * 144 + ch * 16
+                assert _conflict_free(addr), (dy, dx, ch)
