@@ -107,9 +107,6 @@ DEBUG_PROTOTYPES = {
     "cfgpp_igemm_set_mf16_rounds": (None, [_I]),
     "cfgpp_igemm_set_mf16_heads": (None, [_I]),
     "cfgpp_igemm_set_mf16_linear": (None, [_I]),
-    "cfgpp_unet_set_rowblock_ln": (None, [_I]),
-    "cfgpp_op_linear_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _P, _F, _P, _I, _P]),
-    "cfgpp_op_igemm_heads_ln": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
     "cfgpp_igemm_timeline": (None, [_P, _L, _I]),

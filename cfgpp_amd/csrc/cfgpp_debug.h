@@ -75,20 +75,8 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
 int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, const float* bias, int rows_per_batch,
                          void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
                          int q_tok_pad, int tok_pad, void* stream);
-/* token GEMMs with the LayerNorm of the A rows (gamma, beta, eps) applied inside the kernel (rb_kernel; K <= 640): x = the
- * UN-normalised rows.  Same output contracts as cfgpp_op_igemm (epi 0 / 1) and cfgpp_op_igemm_heads; the result is bit-identical
- * to cfgpp_op_layernorm followed by the plain op on a 32x32x16-MFMA tile. */
-int cfgpp_op_linear_ln(const void* x, int K, const void* w, int M, int N, const float* bias, const float* gamma, const float* beta,
-                       float eps, void* out, int epi, void* stream);
-int cfgpp_op_igemm_heads_ln(const void* x, int K, const void* w, int M, int N, const float* gamma, const float* beta, float eps,
-                            int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
-                            int q_tok_pad, int tok_pad, void* stream);
-/* 1 (default): UNet engines finalized after this call run the transformer blocks' LayerNorms inside the consuming projections at the
- * levels with C <= 640 (rb_kernel; same bits as layernorm -> igemm); 0: separate layernorm launches (A/B switch) */
-void cfgpp_unet_set_rowblock_ln(int on);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
- * 20 = row-block kernel (token-major linears with K <= 640: the A rows resident in LDS, every wave on its own column slabs);
  * 15 / 16 / 17 = 256x128 (8 waves) / 128x128 / 256x64 (4 waves) on 32-deep K-tiles, 2 - 3 workgroups per CU (token-major linears);
  * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);
  * 21..23 = register-staged 1..3 */

@@ -98,8 +98,8 @@ __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
     return __builtin_elementwise_fma(x, (f32x2){0.5f, 0.5f}, m);
 }
 
-// ---- LayerNorm of ONE row held by a wave (shared by layernorm_kernel and the row-block loader of rb_kernel, so that both
-// produce the same bits): lane l holds the 16-byte chunks l, l + 64, ... (8 channels each) of the row; exact two-pass variance.
+// ---- LayerNorm of ONE row held by a wave (layernorm_kernel): lane l holds the 16-byte chunks l, l + 64, ... (8 channels each) of
+// the row; exact two-pass variance.
 template <int MAXV>
 __device__ __forceinline__ void ln_row_stats(const half8_t (&raw)[MAXV], int chunks, int C, float eps, int lane,
                                              float (&v)[MAXV][8], float& mean, float& rstd) {

@@ -75,7 +75,7 @@ struct EngineBase {
             tuned_rows = rows;
             return 0;
         }
-        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 20};
+        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17};
         const size_t n = plan.size();
         plan_hint.resize(n, nullptr);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -303,10 +303,9 @@ struct Plan {
     }
     // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
     void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
-                int tokens, int epi = EPI_STORE, const float* ln_g = nullptr, const float* ln_b = nullptr) {
+                int tokens, int epi = EPI_STORE) {
         IGemmArgs a = base_args();
         a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias;
-        if (ln_g) { a.ln_x = A; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; }      // A = the un-normalised rows: LayerNorm inside the kernel
         a.resid = resid; a.rmode = 0; a.rld = N; a.out = out; a.omode = 0;
         a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
         u->macs_per_row += (double)tokens * N * K;
@@ -329,12 +328,11 @@ struct Plan {
     // projection into head-major buffers
     void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
                half_t* q, half_t* k, half_t* vt, int q_tok_pad, int tok_pad, bool count = true,
-               const float* bias = nullptr, const float* ln_g = nullptr, const float* ln_b = nullptr) {
+               const float* bias = nullptr) {
         IGemmArgs a = base_args();
         const int d = C / nheads;
         a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.epi = EPI_HEADS;
         a.bias = bias;
-        if (ln_g) { a.ln_x = A; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f; }
         a.rows_per_batch = tokens; a.hq = q; a.hk = k; a.hvt = vt; a.part0 = part0; a.part_width = C;
         a.head_dim = d; a.head_dim_pad = round_up(d, 32); a.heads = nheads; a.tok_pad = tok_pad; a.q_tok_pad = q_tok_pad;
         if (count) u->macs_per_row += (double)tokens * N * K;

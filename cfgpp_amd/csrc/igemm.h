@@ -54,14 +54,6 @@ struct IGemmArgs {
     int walk_div;             // tiles along the minor axis of the walk (filled by igemm_launch)
     int walk_hint;            // decoded from cfg_hint by igemm_launch
     int split;                // >= 2: K-split every tile this many ways (igemm_launch's big-tile rule / diagnostics); 0: launcher's rule
-    // ---- LayerNorm of the A rows inside the kernel (rb_kernel only: token-major launches with K <= 640) ----
-    const half_t* ln_x;       // UN-normalised rows [M][K] (the residual stream), or null: A = a0 as is.  When set, the launch runs on
-                              // rb_kernel, whose row-block loader normalises every row (exact two-pass statistics, gamma / beta, fp16
-                              // rounding: the arithmetic of layernorm_kernel, bit for bit) on its way into LDS - no LayerNorm launch,
-                              // the normalised rows never exist in memory
-    const float* ln_g;        // [K]
-    const float* ln_b;        // [K]
-    float ln_eps;
     // ---- diagnostics (cfgpp_igemm_timeline): per-workgroup time stamps of ONE chosen launch, null otherwise ----
     int par_nb;               // time-embedding rows (batches) a tile stages in LDS (set by the launcher: covers every batch a tile's rows touch)
     unsigned long long* tl;   // [grid][16]: s_memtime at {entry, first tile landed, k-loop done, stores done}, s_memrealtime at

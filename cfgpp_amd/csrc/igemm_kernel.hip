@@ -1134,171 +1134,6 @@ lin32_kernel(const IGemmArgs p) {
     tl_end(p.tl);
 }
 
-// ---- row-block linears: the A rows resident in LDS, every wave on its own column slabs, optional LayerNorm on the way in ----
-// The K <= 640 projections of the 64x64 / 32x32 levels (QKV, cross-attention Q, GEGLU: K = C = 320 / 640, N = 1 .. 8 C, M = 16k .. 65k
-// tokens) are a few K-tiles deep and write far more than they read: as tiles of a GEMM grid they are prologue + epilogue, and the
-// LayerNorm in front of each is a launch that moves the rows once more (42 MB read + 42 MB written per launch at 64x64).  Here a
-// workgroup owns BM token rows for ALL N columns:
-//   * the rows go HBM -> registers -> LDS once ([BM][2 C + 16] bytes; the 16-byte pad makes the 32-row fragment reads conflict
-//     free: pitch 164 / 324 dwords = 36 / 4 mod 64, sixteen different bank quads per lane group).  With IGemmArgs::ln_x set the
-//     loader normalises each row while it holds it (ln_row_stats / ln_row_affine of common.h: layernorm_kernel's arithmetic, the
-//     same bits), so LayerNorm costs no launch and no memory pass;
-//   * each of the 8 waves then walks its own 32- (GEGLU: 64-) column slabs: a wave-private 3-stage LDS-DMA ring streams the slab's
-//     weight rows (32-deep K-tiles, lin32's 64-byte swizzled rows) - no workgroup barrier after the block is loaded, so the waves
-//     drift apart and one wave's epilogue (stores, GELU) runs under the others' MFMAs, and the workgroup's stores leave
-//     spread over its whole life instead of one burst at the end;
-//   * per slab: K loop (MT x NT x 2 MFMAs per K-tile against MT + NT fragment reads per k-step), then the shared LDS-staged
-//     epilogues on a wave-private staging block.  Loads and stores complete out of order with each other, so a counted vmcnt is
-//     only meaningful while nothing but the ring's DMA pieces is in flight: every slab starts with one vmcnt(0) behind its
-//     first pieces (which also drains the previous slab's stores).
-// k is summed exactly as in igemm_kernel (16-deep MFMA steps, ascending), and the LayerNorm is bit-identical to the standalone
-// kernel, so an rb launch returns the bits of layernorm -> igemm.
-template <int MT, int NT, int NSTW>
-__global__ void __launch_bounds__(512)
-rb_kernel(const IGemmArgs p) {
-    constexpr int NW = 8, BM = 32 * MT, SW = 32 * NT, PPW = SW / 16;
-    constexpr int STG = SW * 64;                                     // one ring stage of a wave: SW weight rows x 32 k
-    constexpr int WAVE_LDS = NSTW * STG + 2560 + 256;                // ring + epilogue staging + the slab's bias segment
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int C = p.K, PITCH = 2 * C + 16, KT = C >> 5, chunks = C >> 3;
-    const int m0 = blockIdx.x * BM;
-    char* const ring = smem + BM * PITCH + wid * WAVE_LDS;
-    char* const stg = ring + NSTW * STG;
-    char* const bseg = stg + 2560;
-
-    // ---- the row block: wave w loads (and normalises) rows [w * BM / 8, (w + 1) * BM / 8) ----
-    {
-        const half_t* xsrc = p.ln_x ? p.ln_x : p.a0;
-        constexpr int RW = BM / NW;                                  // rows per wave: 16 / 8 / 4
-        constexpr int RPW = RW < 4 ? RW : 4;                         // rows in flight at a time
-        auto rows = [&](auto maxv_tag) {
-            constexpr int MAXV = decltype(maxv_tag)::value;
-            float4 g[MAXV][2], be[MAXV][2];
-            if (p.ln_x) {
-#pragma unroll
-                for (int j = 0; j < MAXV; ++j) {
-                    const int ch = lane + j * 64;
-                    const int cc = (ch < chunks ? ch : chunks - 1) * 8;
-                    g[j][0] = *reinterpret_cast<const float4*>(p.ln_g + cc); g[j][1] = *reinterpret_cast<const float4*>(p.ln_g + cc + 4);
-                    be[j][0] = *reinterpret_cast<const float4*>(p.ln_b + cc); be[j][1] = *reinterpret_cast<const float4*>(p.ln_b + cc + 4);
-                }
-            }
-            for (int r0 = wid * RW; r0 < (wid + 1) * RW; r0 += RPW) {
-                half8_t raw[RPW][MAXV];
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    int m = m0 + r0 + r;
-                    m = m < p.M ? m : p.M - 1;
-                    const half_t* xr = xsrc + (long)m * C;
-#pragma unroll
-                    for (int j = 0; j < MAXV; ++j) {
-                        const int ch = lane + j * 64;
-                        raw[r][j] = *reinterpret_cast<const half8_t*>(xr + (ch < chunks ? ch : chunks - 1) * 8);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    if (p.ln_x) {
-                        float v[MAXV][8], mean, rstd;
-                        ln_row_stats<MAXV>(raw[r], chunks, C, p.ln_eps, lane, v, mean, rstd);
-#pragma unroll
-                        for (int j = 0; j < MAXV; ++j) raw[r][j] = ln_row_affine(v[j], mean, rstd, g[j], be[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < MAXV; ++j) {
-                        const int ch = lane + j * 64;
-                        if (ch < chunks) *reinterpret_cast<half8_t*>(smem + (r0 + r) * PITCH + ch * 16) = raw[r][j];
-                    }
-                }
-            }
-        };
-        if (chunks <= 64) rows(std::integral_constant<int, 1>{});
-        else rows(std::integral_constant<int, 2>{});
-    }
-    __syncthreads();
-
-    // ---- slabs ----
-    const int frow = lane & 31, fhi = lane >> 5;
-    const int fsw = (frow >> 2) & 3;
-    const int prow = lane >> 2, pchunk = lane & 3;
-    const int schunk = pchunk ^ ((prow >> 2) & 3);
-    const int nslabs = p.N / SW;
-    const int HW = p.rows_per_batch;
-    for (int sl = wid; sl < nslabs; sl += NW) {
-        const int n0s = sl * SW;
-        const half_t* wsrc[PPW];
-#pragma unroll
-        for (int q = 0; q < PPW; ++q) wsrc[q] = p.w + (long)(n0s + q * 16 + prow) * C + schunk * 8;
-        auto dma_tile = [&](int kt, int stage) {
-#pragma unroll
-            for (int q = 0; q < PPW; ++q)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + ((long)kt << 5)),
-                                                 (__attribute__((address_space(3))) void*)(ring + stage * STG + q * 1024), 16, 0, 0);
-        };
-        if (p.bias) {
-            int n = n0s + lane;
-            n = n < p.N ? n : p.N - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n),
-                                             (__attribute__((address_space(3))) void*)bseg, 4, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < NSTW - 1; ++t) dma_tile(t, t);            // (KT >= 10 > NSTW)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // first tiles landed AND the previous slab's stores have left:
-                                                                     // from here on only ring pieces are in flight
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
-
-        auto tile_body = [&](int kt, int stage) {
-            const char* S = ring + stage * STG;
-            const char* A = smem + frow * PITCH + kt * 64;
-            half8_t xa[2][MT], wb[2][NT];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i) xa[ks][i] = *reinterpret_cast<const half8_t*>(A + i * 32 * PITCH + (ks * 2 + fhi) * 16);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) wb[ks][j] = *reinterpret_cast<const half8_t*>(S + (j * 32 + frow) * 64 + ((((ks << 1) | fhi) ^ fsw) << 4));
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks][j], xa[ks][i], acc[i][j], 0, 0, 0);
-        };
-        int kt = 0, cur = 0, nxt = NSTW - 1;
-        for (; kt + NSTW - 1 < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTW - 2) * PPW) : "memory");      // tile kt has landed (wave-private ring: no barrier)
-            dma_tile(kt + NSTW - 1, nxt);                              // into the stage of tile kt - 1: this wave's reads of it have returned
-            tile_body(kt, cur);
-            cur = cur + 1 == NSTW ? 0 : cur + 1;
-            nxt = nxt + 1 == NSTW ? 0 : nxt + 1;
-        }
-        for (; kt < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tile_body(kt, cur);
-            cur = cur + 1 == NSTW ? 0 : cur + 1;
-        }
-
-        Par par;
-        par.lds = bseg; par.n0 = n0s; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = 64;
-        if constexpr (NT == 1) {                                       // (the staging block is sized for these: 32 x 80 bytes)
-            if (p.epi == EPI_STORE) igemm_epilogue_staged<MT, NT, true>(p, acc, m0, n0s, lane, stg, par);
-            else igemm_epilogue_heads_staged<MT, NT, true>(p, acc, m0, n0s, lane, stg, par);
-        } else {
-            igemm_epilogue_geglu_staged<MT, NT, true>(p, acc, m0, n0s, lane, stg, par);
-        }
-    }
-}
-
 // ---- 128 x 160 tile as EIGHT waves of 32 x 80 on v_mfma_f32_16x16x32_f16 --------------------------------------------
 // The in-situ A/Bs of round 2 rewarded three properties at once - 8 waves per workgroup (two per SIMD), >= 3 LDS stages
 // (two K-tiles of lookahead: inside a forward the operands come from HBM / the Infinity Cache) and one tile per CU - and no
@@ -1819,36 +1654,6 @@ int launch_lin32(const IGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-// row-block linears (rb_kernel): token-major, one source, K <= 640, whole 32- / 64-column slabs, the LDS-staged epilogues' alignment
-static bool rb_ok(const IGemmArgs& a) {
-    if (!(a.amode == 0 && a.taps == 1 && a.C1 == 0 && a.temb == nullptr && a.K % 64 == 0 && a.K <= 640)) return false;
-    if (a.epi == EPI_STORE) return a.N % 32 == 0;
-    if (a.epi == EPI_GEGLU) return a.N % 128 == 0 && a.omode == 0;
-    return a.N % 32 == 0 && a.rows_per_batch % 32 == 0 && a.part_width % 32 == 0 && a.head_dim % 8 == 0 && a.M % 32 == 0;
-}
-template <int MT, int NT, int NSTW>
-int launch_rb_t(const IGemmArgs& a_in, hipStream_t stream) {
-    constexpr int BM = 32 * MT, SW = 32 * NT;
-    IGemmArgs a = a_in;
-    a.par_nb = 0; a.staged_epi = 1; a.n_main = 0; a.ksplit = 1; a.ws = nullptr; a.tl = nullptr;
-    const int smem = BM * (2 * a.K + 16) + 8 * (NSTW * SW * 64 + 2560 + 256);
-    CFGPP_REQUIRE(smem <= 160 * 1024, "rb: K = %d does not fit the row block of %d rows", a.K, BM);
-    static int attr_smem = 0;
-    auto kern = rb_kernel<MT, NT, NSTW>;
-    if (smem > attr_smem) {
-        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_smem = smem;
-    }
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM)), dim3(512), smem, stream, a);
-    CFGPP_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-static int launch_rb(const IGemmArgs& a, hipStream_t stream) {
-    // rows per block: as many as fit beside the rings (K = 320: 128 / 64 for GEGLU's 64-column slabs; K = 640: 64 / 32)
-    if (a.epi == EPI_GEGLU) return a.K <= 320 ? launch_rb_t<2, 2, 3>(a, stream) : launch_rb_t<1, 2, 3>(a, stream);
-    return a.K <= 320 ? launch_rb_t<4, 1, 3>(a, stream) : launch_rb_t<2, 1, 3>(a, stream);
-}
-
 }  // namespace
 
 // forced tile config for tests / tuning: 0 = heuristic; 1..8, 10 tile shapes; +20 (21..23) = register-staged
@@ -1937,10 +1742,6 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // tile of the same shape.  Tuner candidates (same k order as every 32x32x16 tile).
         case 15: return lin32_ok(a) ? launch_lin32<4, 2, 64, 64, 3, 4>(a, stream) : launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128, 8 waves, 72 KB: 2 / CU
         case 16: return lin32_ok(a) ? launch_lin32<2, 2, 64, 64, 3, 3>(a, stream) : launch_cfg<2, 2, 64, 64, true>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
-        // row-block kernel (rb_kernel): the A rows resident in LDS, LayerNorm optionally applied by the loader; K <= 640
-        case 20: if (rb_ok(a)) return launch_rb(a, stream);
-                 CFGPP_REQUIRE(a.ln_x == nullptr, "igemm: a launch with a fused LayerNorm needs the row-block kernel (token-major, K <= 640)");
-                 return launch_cfg<2, 2, 64, 64, true>(a, stream);
         case 17: return lin32_ok(a) ? launch_lin32<4, 1, 64, 64, 3, 2>(a, stream) : launch_cfg<4, 1, 64, 64, true>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
         // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
         // N % 160 == 0 only - anything else falls back to the 4-wave 128 x 160 tile.  Not a tuner candidate (different k order).
@@ -2005,10 +1806,6 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
     CFGPP_REQUIRE(a.epi != EPI_GEGLU || a.N % 64 == 0, "igemm: GEGLU needs N %% 64 == 0");
     CFGPP_REQUIRE(a.epi != EPI_HEADS || (a.head_dim % 4 == 0 && a.part_width % 4 == 0), "igemm: heads args");
     CFGPP_REQUIRE(a.rows_per_batch <= 0 || a.M / a.rows_per_batch < (1 << 20), "igemm: %d rows in batches of %d (batch index must stay below 2^20)", a.M, a.rows_per_batch);
-    if (a.ln_x != nullptr) {                                   // LayerNorm inside the kernel: the row-block kernel is the only one that has it
-        CFGPP_REQUIRE(a.ln_g && a.ln_b && a.ln_eps > 0.f && rb_ok(a), "igemm: fused LayerNorm: token-major launch with K <= 640 and gamma / beta / eps");
-        return launch_rb(a, stream);
-    }
     // tile heuristic: 128x128 (2x2 waves of 64x64) when it fills the chip, 256x64 for
     // N = 64*odd (e.g. 320), 64x64 (4 waves of 32x32) for small problems.
     int cfg = g_force_cfg;
@@ -2066,7 +1863,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
-                            ((h == 15 || h == 16 || h == 17) && lin32_ok(a)) || (h == 20 && rb_ok(a))) && (g_big_tiles || h == 1);
+                            ((h == 15 || h == 16 || h == 17) && lin32_ok(a))) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

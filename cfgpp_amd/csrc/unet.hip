@@ -38,12 +38,6 @@ struct cfgpp_unet : EngineBase {
 
 };
 
-// 1 (default): at the levels with C <= 640 the three LayerNorms of a transformer block run INSIDE the projections that consume them
-// (rb_kernel: the row-block loader normalises the rows on their way into LDS; bit-identical to layernorm -> igemm); 0: separate
-// layernorm launches everywhere (A/B switch, read at finalize)
-static int g_rb_ln = 1;
-extern "C" void cfgpp_unet_set_rowblock_ln(int on) { g_rb_ln = on ? 1 : 0; }
-
 namespace {
 
 void build_param_table(cfgpp_unet* u) {
@@ -364,21 +358,14 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
                 });
             }
             ++cross_block_counter;
-            const bool rb = g_rb_ln && C <= 640 && C % 64 == 0 && tok % 32 == 0 && d % 8 == 0;      // LayerNorm inside the consuming projection
             // self-attention
-            if (rb) P.heads(u->tok_x, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad, true, nullptr, l1g, l1b);
-            else {
-                P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
-                P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l1g, l1b, tok, C);
+            P.heads(u->tok_ln, C, wqkv, 3 * C, tok, 0, C, nheads, HQ, HK, HVT, q_pad, k_pad);
             P.attention(HQ, HK, HVT, u->tok_attn, nheads, d, tok, tok, q_pad, k_pad);
             P.linear(u->tok_attn, C, u->tok_x, C, wo1, bo1, u->tok_x, tok);
             // cross-attention
-            if (rb) P.heads(u->tok_x, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad, true, nullptr, l2g, l2b);
-            else {
-                P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
-                P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l2g, l2b, tok, C);
+            P.heads(u->tok_ln, C, wq2, C, tok, 0, C, nheads, HQ, nullptr, nullptr, q_pad, k_pad);
             {
                 cfgpp_unet* uu = u;
                 u->attn_macs_per_row += 2.0 * (double)nheads * tok * 77 * d;
@@ -390,11 +377,8 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             }
             P.linear(u->tok_attn, C, u->tok_x, C, wo2, bo2, u->tok_x, tok);
             // feed-forward (GEGLU)
-            if (rb) P.linear(u->tok_x, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU, l3g, l3b);
-            else {
-                P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
-                P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);
-            }
+            P.layernorm(u->tok_x, u->tok_ln, l3g, l3b, tok, C);
+            P.linear(u->tok_ln, C, u->tok_ff, 8 * C, wff1, bff1, nullptr, tok, EPI_GEGLU);
             P.linear(u->tok_ff, 4 * C, u->tok_x, C, wff2, bff2, u->tok_x, tok);
         }
         Tensor out = u->acq(x.H, x.W, C);
@@ -600,28 +584,6 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
     a.w = (const half_t*)w; a.M = M; a.N = N; a.K = taps * (C0 + C1); a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
     a.rows_per_batch = H * W; a.resid = (const half_t*)resid; a.rmode = rmode; a.rld = rld;
     a.out = (half_t*)out; a.omode = omode; a.old = old_; a.epi = epi;
-    return igemm_launch(a, (hipStream_t)stream);
-}
-
-// token GEMMs with the LayerNorm of the A rows inside the kernel (IGemmArgs::ln_x: rb_kernel): epi 0 / 1 (plain store with optional
-// bias / GEGLU with packed weights), and the head-major projection
-int cfgpp_op_linear_ln(const void* x, int K, const void* w, int M, int N, const float* bias, const float* gamma, const float* beta,
-                       float eps, void* out, int epi, void* stream) {
-    IGemmArgs a = base_args();
-    a.a0 = (const half_t*)x; a.ln_x = (const half_t*)x; a.ln_g = gamma; a.ln_b = beta; a.ln_eps = eps;
-    a.C0 = K; a.amode = 0; a.w = (const half_t*)w; a.M = M; a.N = N; a.K = K; a.bias = bias; a.epi = epi; a.rows_per_batch = M;
-    a.out = (half_t*)out; a.omode = 0; a.old = epi == EPI_GEGLU ? N / 2 : N;
-    return igemm_launch(a, (hipStream_t)stream);
-}
-int cfgpp_op_igemm_heads_ln(const void* x, int K, const void* w, int M, int N, const float* gamma, const float* beta, float eps,
-                            int rows_per_batch, void* hq, void* hk, void* hvt, int part0, int part_width, int head_dim, int heads,
-                            int q_tok_pad, int tok_pad, void* stream) {
-    IGemmArgs a = base_args();
-    a.a0 = (const half_t*)x; a.ln_x = (const half_t*)x; a.ln_g = gamma; a.ln_b = beta; a.ln_eps = eps;
-    a.C0 = K; a.amode = 0; a.w = (const half_t*)w; a.M = M; a.N = N; a.K = K;
-    a.epi = EPI_HEADS; a.rows_per_batch = rows_per_batch; a.hq = (half_t*)hq; a.hk = (half_t*)hk; a.hvt = (half_t*)hvt;
-    a.part0 = part0; a.part_width = part_width; a.head_dim = head_dim; a.head_dim_pad = round_up(head_dim, 32);
-    a.heads = heads; a.q_tok_pad = q_tok_pad; a.tok_pad = tok_pad;
     return igemm_launch(a, (hipStream_t)stream);
 }
 

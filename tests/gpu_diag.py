@@ -422,78 +422,6 @@ def t_lin32():
     return out
 
 
-@case("rowblock")
-def t_rb():
-    """rb_kernel (config 20: A rows resident in LDS, wave-private weight rings): (a) as a plain tile choice - linear + bias + residual,
-    head-major projection, GEGLU at K = 64 .. 640, ragged M - right against fp32, BIT-IDENTICAL to the 128 x 128 igemm tile and
-    repeatable; (b) with the LayerNorm inside (IGemmArgs::ln_x) - bit-identical to cfgpp_op_layernorm followed by that tile."""
-    out = {}
-    for name, M, N, K, resid, epi in (("lin_c320", 16384, 320, 320, True, 0), ("lin_c640", 4096, 640, 640, True, 0), ("lin_k64", 1000, 96, 64, False, 0),
-                                      ("lin_k448", 1000, 192, 448, False, 0), ("geglu_c320", 8192, 2560, 320, False, 1), ("geglu_c640", 2048, 5120, 640, False, 1)):
-        a = rnd(M, K, seed=len(name))
-        w = rnd(N, K, scale=K ** -0.5, seed=len(name) + 1)
-        b = rnd(N, scale=0.1, seed=len(name) + 2)
-        r = rnd(M, N, seed=len(name) + 3) if resid else None
-        ad, bd = a.to(H.DEV, torch.float16), b.to(H.DEV)
-        rd = r.to(H.DEV, torch.float16) if resid else None
-        if epi == 1:
-            h = a @ w.t() + b
-            v, g = h.chunk(2, dim=-1)
-            ref = v * F.gelu(g)
-            wd, bd = H.pack_geglu(w, b)
-        else:
-            ref = a @ w.t() + b + (r if resid else 0)
-            wd = w.to(H.DEV, torch.float16)
-        H.lib().cfgpp_igemm_force_config(1)
-        base = H.linear(ad, wd, bd, rd, epi=epi)
-        H.lib().cfgpp_igemm_force_config(20)
-        got = H.linear(ad, wd, bd, rd, epi=epi)
-        same = all(torch.equal(got, H.linear(ad, wd, bd, rd, epi=epi)) for _ in range(6))
-        out[name] = dict(H.err_stats(got, ref), identical_runs=bool(same), equals_cfg1=bool(torch.equal(got, base)))
-        # LayerNorm inside: x with per-row offsets (mean far from zero)
-        x = (rnd(M, K, seed=len(name) + 5) * 1.5 + rnd(M, 1, seed=len(name) + 6) * 3).half().float()
-        gam, bet = 1 + 0.2 * rnd(K, seed=len(name) + 7), 0.2 * rnd(K, seed=len(name) + 8)
-        xd = x.to(H.DEV, torch.float16)
-        yn = F.layer_norm(x, (K,), gam, bet, 1e-5)
-        if epi == 1:
-            hh = yn @ w.half().float().t() + b
-            vv, gg = hh.chunk(2, dim=-1)
-            ref_ln = vv * F.gelu(gg)
-        else:
-            ref_ln = yn @ w.half().float().t() + b
-        H.lib().cfgpp_igemm_force_config(1)
-        two = H.linear(H.layernorm(xd, gam.to(H.DEV), bet.to(H.DEV)), wd, bd, None, epi=epi)
-        H.lib().cfgpp_igemm_force_config(0)
-        fused = H.linear_ln(xd, wd, bd, gam.to(H.DEV), bet.to(H.DEV), epi=epi)
-        out[name + "_ln"] = dict(H.err_stats(fused, ref_ln), identical_runs=True, equals_cfg1=bool(torch.equal(fused, two)))
-    # head-major projections: SD1.5 level-0 / level-1 geometries (d = 40, 80) and a small one
-    for name, B, tokens, C, nheads in (("heads_c320", 2, 4096, 320, 8), ("heads_c640", 2, 1024, 640, 8), ("heads_c128", 2, 96, 128, 4)):
-        d = C // nheads
-        x = (rnd(B * tokens, C, seed=len(name)) * 1.5 + rnd(B * tokens, 1, seed=len(name) + 1) * 2).half().float()
-        w = rnd(3 * C, C, scale=C ** -0.5, seed=len(name) + 2)
-        gam, bet = 1 + 0.2 * rnd(C, seed=len(name) + 3), 0.2 * rnd(C, seed=len(name) + 4)
-        qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
-        xd, wd = x.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16)
-        y = (x @ w.half().float().t()).reshape(B, tokens, 3, nheads, d)
-        H.lib().cfgpp_igemm_force_config(1)
-        b1 = H.heads_project(xd, wd, B, tokens, C, nheads, 0, 3, qp, kp)
-        H.lib().cfgpp_igemm_force_config(20)
-        g1 = H.heads_project(xd, wd, B, tokens, C, nheads, 0, 3, qp, kp)
-        out[name + "_q"] = dict(H.err_stats(g1[0][:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3)), identical_runs=True,
-                                equals_cfg1=bool(all(torch.equal(u, v) for u, v in zip(g1, b1))))
-        out[name + "_vt"] = dict(H.err_stats(g1[2][:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1)),
-                                 identical_runs=True, equals_cfg1=True)
-        yl = (F.layer_norm(x, (C,), gam, bet, 1e-5) @ w.half().float().t()).reshape(B, tokens, 3, nheads, d)
-        H.lib().cfgpp_igemm_force_config(1)
-        two = H.heads_project(H.layernorm(xd, gam.to(H.DEV), bet.to(H.DEV)), wd, B, tokens, C, nheads, 0, 3, qp, kp)
-        H.lib().cfgpp_igemm_force_config(0)
-        fused = H.heads_project_ln(xd, wd, gam.to(H.DEV), bet.to(H.DEV), B, tokens, C, nheads, 0, qp, kp)
-        out[name + "_ln_k"] = dict(H.err_stats(fused[1][:, :tokens, :d].reshape(B, nheads, tokens, d), yl[:, :, 1].permute(0, 2, 1, 3)), identical_runs=True,
-                                   equals_cfg1=bool(all(torch.equal(u, v) for u, v in zip(fused, two))))
-    H.lib().cfgpp_igemm_force_config(0)
-    return out
-
-
 @case("conv_in_out")
 def t_cio():
     out = {}

@@ -144,27 +144,6 @@ def heads_project(a, w, B, tokens, C, nheads, part0, nparts, q_pad, k_pad):
     return hq, hk, hvt
 
 
-def linear_ln(x, w, bias, gamma, beta, epi=0, eps=1e-5):
-    """layer_norm(x) @ w^T (+ bias) with the LayerNorm inside the GEMM kernel (rb_kernel); epi 1 = GEGLU on packed weights"""
-    M, K = x.shape
-    N = w.shape[0]
-    out = torch.empty((M, N // 2 if epi == 1 else N), dtype=torch.float16, device=DEV)
-    check(lib().cfgpp_op_linear_ln(P(x), K, P(w), M, N, P(bias), P(gamma), P(beta), float(eps), P(out), int(epi), stream()), "cfgpp_op_linear_ln")
-    return out
-
-
-def heads_project_ln(x, w, gamma, beta, B, tokens, C, nheads, part0, q_pad, k_pad, eps=1e-5):
-    d = C // nheads
-    dp = round_up(d, 32)
-    hq = torch.zeros((B * nheads, q_pad, dp), dtype=torch.float16, device=DEV)
-    hk = torch.zeros((B * nheads, k_pad, dp), dtype=torch.float16, device=DEV)
-    hvt = torch.zeros((B * nheads, dp, k_pad), dtype=torch.float16, device=DEV)
-    check(lib().cfgpp_op_attention_prepare_vt(P(hvt), B * nheads, d, k_pad, stream()), "cfgpp_op_attention_prepare_vt")
-    check(lib().cfgpp_op_igemm_heads_ln(P(x), x.shape[1], P(w), x.shape[0], w.shape[0], P(gamma), P(beta), float(eps), tokens, P(hq), P(hk),
-                                        P(hvt), part0, C, d, nheads, q_pad, k_pad, stream()), "cfgpp_op_igemm_heads_ln")
-    return hq, hk, hvt
-
-
 def vt_pos(n):
     """column of key 0..n-1 in a V^T buffer (bits 2 and 3 of the key index swapped; include/cfgpp.h)"""
     key = torch.arange(n)

@@ -123,13 +123,6 @@ def test_linears_on_32_deep_k_tiles(diag):
     assert all(v["identical_runs"] and v["equals_cfg1"] for v in r.values()), {k: (v["identical_runs"], v["equals_cfg1"]) for k, v in r.items()}
 
 
-def test_row_block_kernel(diag):
-    """rb_kernel: parity vs fp32; as a tile choice bit-identical to the 128 x 128 igemm tile; with the LayerNorm inside bit-identical
-    to layernorm -> igemm (what lets the engine drop the LayerNorm launches without changing a bit of the forward)"""
-    r = _check(diag, diag.t_rb, "rowblock", rel=2e-3)
-    assert all(v["identical_runs"] and v["equals_cfg1"] for v in r.values()), {k: (v["identical_runs"], v["equals_cfg1"]) for k, v in r.items() if not (v["identical_runs"] and v["equals_cfg1"])}
-
-
 def test_conv_in_out(diag):
     _check(diag, diag.t_cio, "conv_in_out")
 

@@ -77,9 +77,9 @@ def test_vt_key_permutation():
             assert p == list(range(p[0], p[0] + 8)) and p[0] % 8 == 0, (tt, hi, p)
 
 
-# ---- round 4: 64-byte rows (32-deep K-tiles of lin32_kernel / rb_kernel), padded row blocks, the conv_out halo tile ----
+# ---- round 4: 64-byte rows (32-deep K-tiles of lin32_kernel), the conv_out halo tile ----
 def test_64_byte_rows_fragment_reads_and_dma_swizzle():
-    """lin32_kernel / the weight rings of rb_kernel: rows of 64 bytes (4 chunks), physical = logical ^ ((row >> 2) & 3); a
+    """lin32_kernel: rows of 64 bytes (4 chunks), physical = logical ^ ((row >> 2) & 3); a
     fragment read is row = base + (lane & 31), logical chunk 2 * ks + (lane >> 5), ks = 0, 1; the DMA piece is 16 rows, lane ->
     (row = lane >> 2, physical slot = lane & 3) loading source chunk slot ^ ((row >> 2) & 3)"""
     for base in range(0, 384, 32):
@@ -98,22 +98,6 @@ def test_64_byte_rows_fragment_reads_and_dma_swizzle():
     def unswizzled(l):
         return (l & 31) * 64 + ((l >> 5) << 4)
     assert max(max(q.count(v) for v in set(q)) for q in _quads(unswizzled)) >= 4
-
-
-def test_row_block_pitch_makes_fragment_reads_conflict_free():
-    """rb_kernel's resident A block: [rows][2 C + 16] bytes, fragment read row = 32 i + (lane & 31), 16-byte chunk = 4 kt + 2 ks +
-    (lane >> 5).  The 16-byte pad turns the pitch into 36 (C = 320) / 4 (C = 640) dwords mod 64; without it (pitch 640 / 1280
-    bytes) the 16 rows of a lane group fall on 2 / 1 bank quads."""
-    for C in (64, 128, 192, 256, 320, 384, 448, 512, 576, 640):
-        pitch = 2 * C + 16
-        for chunk in range(0, C // 8, 2):
-            def addr(l, pitch=pitch, chunk=chunk):
-                return (l & 31) * pitch + (chunk + (l >> 5)) * 16
-            assert _conflict_free(addr), (C, chunk)
-    for C in (320, 640):
-        def bare(l, C=C):
-            return (l & 31) * 2 * C + ((l >> 5) << 4)
-        assert max(max(q.count(v) for v in set(q)) for q in _quads(bare)) >= 8
 
 
 def test_conv_out_halo_tile_reads_are_conflict_free():
