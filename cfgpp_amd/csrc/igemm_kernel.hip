@@ -966,33 +966,34 @@ igemm_reduce_kernel(const IGemmArgs p) {
     igemm_epilogue<1, 1, false>(p, acc, tile_m * BM + wm * WTM + i * 32, tile_n * BN + wn * WTN + j * 32, lane, par);
 }
 
-// ---- token-major linears on 32-deep K-tiles: TWO (or three) workgroups per CU -----------------------------------------------
-// The round-3 timelines of the K <= 1280 projections (QKV / Q heads, to_out, GEGLU, FF-out, proj_in / proj_out: a third of an
-// SD1.5 forward's igemm time at 290 - 620 TF/s) show what one 8-wave workgroup per CU costs them: a workgroup is prologue
-// (2 - 4 us: kernel arguments, index math, first tiles in flight) -> K loop (5 - 20 K-tiles) -> epilogue (5 - 15 us: every CU
-// bursts its stores and residual reads at the same time, 3.5 - 5.5 TB/s chip-wide), and while a CU is in the first or the last
-// phase its matrix pipe idles - half of the workgroup's life at K = 320.  The tiles above cannot share a CU: 64-deep K-tiles on
-// a 2 / 3-stage ring are 96 - 156 KB of LDS.  Here a K-tile is 32 deep: LDS rows of 64 bytes, (BM + BN) * 64 bytes per stage,
-// 72 KB for a 256 x 128 tile on a 3-stage ring -> two workgroups (16 waves, 128 VGPRs each) per CU, so one workgroup's
-// prologue / epilogue runs under the other one's MFMAs and the chip's store bursts de-synchronise.
-//   * token-major A only (amode 0: a row of A is K contiguous halfs, like a row of W): every LDS-DMA piece - 16 rows x 64 B,
-//     lane -> (row = lane >> 2, 16-byte chunk = lane & 3) - advances by the same 64 bytes per K-tile, whichever operand it
-//     belongs to; a wave's PPW pieces are precomputed (source pointer per lane, wave-uniform LDS offset).
-//   * swizzle: physical chunk = logical chunk ^ ((row >> 2) & 3), applied to the DMA's SOURCE chunk.  A fragment read (rows
-//     base + (lane & 31), logical chunk 2 * kstep + (lane >> 5)) then touches, per 16-lane group, 16 rows whose
-//     (row & 3, (row >> 2) & 3) pairs are all different: bank quad 16 * (row & 3) + 4 * (chunk ^ ((row >> 2) & 3)) - conflict free.
-//   * one barrier per K-tile (8 MFMAs per wave on the 64 x 64 wave tile); the 4 waves per SIMD of two workgroups cover it.
-//   * k is summed in the same order as igemm_kernel (16-deep MFMA steps, ascending): results are bit-identical to every other
-//     32x32x16 tile, so the in-situ tuner may pin these (configs 15 / 16 / 17).  Whole tiles only; epilogues shared.
-template <int WM, int WN, int WTM, int WTN, int NST, int WPE>
+// ---- the same GEMM on 32-deep K-tiles (tile32_kernel) --------------------------------------------------------------------
+// A K-tile of 64 fixes the LDS budget of the kernels above at (BM + BN) * 128 bytes per stage: the 256-wide tiles get TWO stages
+// (one tile of lookahead - inside a forward shorter than the memory latency, which is why three stages took over every shape
+// they fit) and one workgroup per CU.  Here a K-tile is 32 deep - LDS rows of 64 bytes, (BM + BN) * 64 bytes per
+// stage - which buys, for the same LDS:
+//   * 256 x 256 / 256 x 320 on a FOUR-stage ring (128 / 147 KB): three half-tiles of lookahead, requested and awaited at twice
+//     the granularity (configs 25 / 26);
+//   * 256 x 128 (8 waves, 72 KB), 128 x 128 and 256 x 64 (4 waves, 48 / 60 KB) on three stages with TWO or THREE workgroups per
+//     CU (configs 15 / 16 / 17): one workgroup's prologue / epilogue runs under another's MFMAs and the chip's store bursts
+//     de-synchronise - what the K <= 1280 projections of the transformer blocks lacked (round-3 timelines: a workgroup is
+//     prologue 2 - 4 us -> 5 - 20 K-tiles -> epilogue 5 - 15 us with every CU bursting its stores at once).
+// Layout: LDS-DMA piece = 16 rows x 64 B, lane -> (row = lane >> 2, 16-byte chunk = lane & 3); swizzle physical = logical ^
+// ((row >> 2) & 3) applied to the DMA's SOURCE chunk; a fragment read (rows base + (lane & 31), logical chunk 2 * kstep +
+// (lane >> 5)) touches, per lane group of a ds_read_b128, 16 rows whose (row & 3, (row >> 2) & 3) pairs are all different:
+// conflict free (tests/test_lds_layout_cpu.py).  The A gather is igemm_kernel's (K-tile kt32 = half (kt32 & 1) of the 64-channel
+// block / tap of kt32 >> 1); piece g = wave + NW * q of a K-tile is an activation piece for g < BM / 16, else a weight piece;
+// when the pieces do not divide over the waves the first (A_P + B_P) % NW waves carry one more, and every counted wait uses the
+// wave's own count.  One barrier per K-tile.  k is summed in igemm_kernel's order (16-deep MFMA steps, ascending): bit-identical
+// results, so the in-situ tuner may pin these.  Whole tiles only; epilogues shared with igemm_kernel.
+template <int WM, int WN, int WTM, int WTN, int NST, int WPE, int AMODE>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-lin32_kernel(const IGemmArgs p) {
+tile32_kernel(const IGemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * WTM, BN = WN * WTN;
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int A_P = BM / 16, B_P = BN / 16;            // 16-row DMA pieces of the two operand tiles
-    constexpr int PPW = (A_P + B_P) / NW;                  // pieces per wave per K-tile
-    static_assert((A_P + B_P) % NW == 0, "pieces must divide over the waves");
+    constexpr int A_P = BM / 16, B_P = BN / 16, TOT = A_P + B_P;      // 16-row DMA pieces of the two operand tiles
+    constexpr int FULL = TOT / NW, REM = TOT % NW, PPW = FULL + (REM ? 1 : 0);
+    constexpr int NM = 2 * MT * NT;                        // MFMAs per wave per K-tile
     constexpr int STAGE_BYTES = (BM + BN) * 64;
     constexpr int PAR_OFF = NST * STAGE_BYTES;             // epilogue parameters behind the ring
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1013,34 +1014,83 @@ lin32_kernel(const IGemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid - wm * WN;
+    const bool extra = REM != 0 && wid < REM;              // (wave-uniform) this wave carries PPW pieces, the others PPW - 1
+    const int HW = p.rows_per_batch;
 
-    // ---- loader: piece g = wid + NW * q of the K-tile; g < A_P: activation rows [16 g, 16 g + 16), else weight rows ----
+    // ---- loader state: per piece slot q, either an activation row (a_pix, gathered per K-tile) or a weight-row pointer ----
     const int prow = lane >> 2, pchunk = lane & 3;
     const int schunk = pchunk ^ ((prow >> 2) & 3);         // the logical chunk that belongs at physical slot pchunk of that row
-    const half_t* src[PPW];
+    int a_pix[PPW];
+    const half_t* b_ptr[PPW];
     int dst[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
         const int g = wid + NW * q;
+        a_pix[q] = 0; b_ptr[q] = p.w;
         if (g < A_P) {
             int m = m0 + g * 16 + prow;
             m = m < p.M ? m : p.M - 1;
-            src[q] = p.a0 + (long)m * p.K + schunk * 8;
+            if constexpr (AMODE == 0) a_pix[q] = m;
+            else if constexpr (AMODE == 1) a_pix[q] = padded_pix(m, HW, p.W, p.H);
+            else if constexpr (AMODE == 2) {
+                const int b = qdiv(m, HW), r2 = m - b * HW, y = qdiv(r2, p.W), x = r2 - y * p.W;
+                a_pix[q] = (b * (2 * p.H + 2) + 2 * y + 1 + p.ashift) * (2 * p.W + 2) + 2 * x + 1 + p.ashift;
+            } else {
+                const int b = qdiv(m, HW), r2 = m - b * HW, y = qdiv(r2, p.W), x = r2 - y * p.W;
+                a_pix[q] = (b << 22) | (y << 11) | x;
+            }
             dst[q] = g * 16 * 64;
         } else {
             int n = n0 + (g - A_P) * 16 + prow;
             n = n < p.N ? n : p.N - 1;
-            src[q] = p.w + (long)n * p.K + schunk * 8;
+            b_ptr[q] = p.w + (long)n * p.K + schunk * 8;
             dst[q] = BM * 64 + (g - A_P) * 16 * 64;
         }
     }
-    auto dma_tile = [&](int kt, int stage) {
-        char* base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int q = 0; q < PPW; ++q)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + ((long)kt << 5)),
-                                             (__attribute__((address_space(3))) void*)(base + dst[q]), 16, 0, 0);
+    struct Gather { const half_t* src; int cs, Cs, dpix, dy, dx; };
+    auto gather_of = [&](int kt) {                          // kt = 32-deep K-tile
+        Gather g;
+        const int k64 = kt >> 1;
+        int tap = 0, cc = k64 << 6;
+        if (p.taps == 9) { const int cb = k64 / 9; tap = k64 - cb * 9; cc = cb << 6; }
+        const bool s0 = cc < p.C0;
+        g.src = s0 ? p.a0 : p.a1;
+        g.cs = (s0 ? cc : cc - p.C0) + ((kt & 1) << 5); g.Cs = s0 ? p.C0 : p.C1;
+        g.dy = 0; g.dx = 0;
+        if (p.taps == 9) { g.dy = tap / 3 - 1; g.dx = tap - (tap / 3) * 3 - 1; }
+        g.dpix = 0;
+        if constexpr (AMODE == 1) g.dpix = g.dy * (p.W + 2) + g.dx;
+        else if constexpr (AMODE == 2) g.dpix = g.dy * (2 * p.W + 2) + g.dx;
+        return g;
     };
+    auto piece = [&](int q, int kt, int stage, const Gather& g) {      // q compile-time after unrolling
+        char* base = smem + stage * STAGE_BYTES;
+        const int gi = wid + NW * q;
+        if (gi < A_P) {
+            int pix;
+            if constexpr (AMODE == 3) {
+                const int b = a_pix[q] >> 22, y = (a_pix[q] >> 11) & 2047, x = a_pix[q] & 2047;
+                const int Hs = p.H >> 1, Ws = p.W >> 1;
+                pix = (b * (Hs + 2) + ((y + g.dy) >> 1) + 1) * (Ws + 2) + ((x + g.dx) >> 1) + 1;
+            } else {
+                pix = a_pix[q] + g.dpix;
+            }
+            const half_t* gp = g.src + (long)pix * g.Cs + g.cs + schunk * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(base + dst[q]), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[q] + ((long)kt << 5)),
+                                             (__attribute__((address_space(3))) void*)(base + dst[q]), 16, 0, 0);
+        }
+    };
+    auto dma_tile = [&](int kt, int stage) {               // all of the wave's pieces back to back (prologue)
+        const Gather g = gather_of(kt);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) if (q < FULL || extra) piece(q, kt, stage, g);
+    };
+    // "at most n K-tiles of THIS wave's pieces still in flight"
+#define CFGPP_T32_WAIT(n) do { if (REM != 0 && extra) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((n) * PPW) : "memory");          \
+                               else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((n) * FULL) : "memory"); } while (0)
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -1062,35 +1112,77 @@ lin32_kernel(const IGemmArgs p) {
     for (int s_ = 0; s_ < NST - 1; ++s_) if (s_ < nk) dma_tile(s_, s_);
     tl_stamp(p.tl, 9);
 
-    auto tile_body = [&](int stage) {
+    // one K-tile: MFMAs on `stage`; with_dma: the wave's pieces of tile ktn go out into stage `nxt`, one after every second MFMA
+    auto tile_body = [&](int stage, int ktn, int nxt, auto with_dma) {
+        constexpr bool DMA = decltype(with_dma)::value;
         const char* S = smem + stage * STAGE_BYTES;
-        half8_t xa[2][MT], wb[2][NT];
+        Gather gn = {p.a0, 0, p.C0, 0, 0, 0};
+        if constexpr (DMA) gn = gather_of(ktn);
+        int issued = 0, done = 0;                          // compile-time after unrolling
+        auto after_mfma = [&]() {
+            ++done;
+            if constexpr (DMA) {
+                if (issued < PPW && done >= 2 * issued + 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (issued < FULL || extra) piece(issued, ktn, nxt, gn);
+                    ++issued;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        if constexpr (MT * NT <= 8) {
+            half8_t xa[2][MT], wb[2][NT];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) xa[ks][i] = *reinterpret_cast<const half8_t*>(S + a_rd + i * 32 * 64 + coff);
+                for (int i = 0; i < MT; ++i) xa[ks][i] = *reinterpret_cast<const half8_t*>(S + a_rd + i * 32 * 64 + coff);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wb[ks][j] = *reinterpret_cast<const half8_t*>(S + b_rd + j * 32 * 64 + coff);
+                for (int j = 0; j < NT; ++j) wb[ks][j] = *reinterpret_cast<const half8_t*>(S + b_rd + j * 32 * 64 + coff);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks][j], xa[ks][i], acc[i][j], 0, 0, 0);
+                        after_mfma();
+                    }
+        } else {
+            // 10 accumulator tiles per wave (256 x 320): one fragment set at a time
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = (((ks << 1) | fhi) ^ fsw) << 4;
+                half8_t xa[MT], wb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xa[i] = *reinterpret_cast<const half8_t*>(S + a_rd + i * 32 * 64 + coff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) wb[j] = *reinterpret_cast<const half8_t*>(S + b_rd + j * 32 * 64 + coff);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                        after_mfma();
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if constexpr (DMA) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[ks][j], xa[ks][i], acc[i][j], 0, 0, 0);
+            for (int q = 0; q < PPW; ++q) if (q >= issued && (q < FULL || extra)) piece(q, ktn, nxt, gn);      // (what did not fit between the MFMAs)
+        }
     };
     // Iteration kt: "tile kt has landed" (at most the NST-2 younger tiles' pieces outstanding) + barrier - which also says every
-    // wave is done reading tile kt-1, whose stage the DMA of tile kt+NST-1 (issued next) overwrites - then the tile's MFMAs.
+    // wave is done reading tile kt-1, whose stage the pieces of tile kt+NST-1 (issued during this tile's MFMAs) overwrite.
     int kt = 0, cur = 0, nxt = NST - 1;                  // stage of tile kt / of tile kt + NST - 1
     for (; kt + NST - 1 < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PPW) : "memory");
+        CFGPP_T32_WAIT(NST - 2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt == 0) tl_stamp(p.tl, 1);
-        dma_tile(kt + NST - 1, nxt);
-        tile_body(cur);
+        tile_body(cur, kt + NST - 1, nxt, std::true_type{});
         if (kt == 0) tl_stamp(p.tl, 7);
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
@@ -1099,14 +1191,14 @@ lin32_kernel(const IGemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        tile_body(cur);
+        tile_body(cur, 0, 0, std::false_type{});
         cur = cur + 1 == NST ? 0 : cur + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (K < 32 * (NST - 1) never happens: K is a multiple of 64)
+#undef CFGPP_T32_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                     // every wave is done with the ring: LDS is free for the epilogue's staging
     tl_stamp(p.tl, 2);
 
-    const int HW = p.rows_per_batch;
     const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
     Par par;
     par.lds = smem + PAR_OFF; par.n0 = n0; par.b0 = HW > 0 ? qdiv(m0, HW) : 0; par.bnp = par_bnp(BN);
@@ -1123,7 +1215,7 @@ lin32_kernel(const IGemmArgs p) {
             return;
         }
     }
-    constexpr bool HEADS_FITS = NW * NT * 2560 <= NST * STAGE_BYTES;
+    constexpr bool HEADS_FITS = NW * NT * 2560 <= NST * STAGE_BYTES && MT * NT <= 8;
     if constexpr (HEADS_FITS) if (p.epi == EPI_HEADS && p.staged_epi && (p.rows_per_batch & 31) == 0 && (p.part_width & 31) == 0 &&
         (p.head_dim & 7) == 0 && (p.N & 31) == 0 && (p.M & 31) == 0) {
         igemm_epilogue_heads_staged<MT, NT, true>(p, acc, mw0, nw0, lane, smem + wid * (NT * 2560), par);
@@ -1627,24 +1719,26 @@ int launch_cfg(const IGemmArgs& a, hipStream_t stream) {
     }
 }
 
-// token-major linears on 32-deep K-tiles (lin32_kernel): amode 0, one source, no time embedding (the transformer blocks' GEMMs)
-static bool lin32_ok(const IGemmArgs& a) { return a.amode == 0 && a.taps == 1 && a.C1 == 0 && a.temb == nullptr; }
-template <int WM, int WN, int WTM, int WTN, int NST, int WPE>
-int launch_lin32(const IGemmArgs& a_in, hipStream_t stream) {
+// 32-deep K-tiles (tile32_kernel): any activation map; whole tiles
+template <int WM, int WN, int WTM, int WTN, int NST, int WPE, int AMODE>
+int launch_tile32_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
-    constexpr int smem = NST * (BM + BN) * 64 + par_bytes(BN, 0);
-    static_assert(smem * (WPE * 4 / (WM * WN)) <= 160 * 1024, "the workgroups that are meant to share a CU do not fit its LDS");
+    constexpr int WGS = WPE * 4 / (WM * WN);              // workgroups that are meant to share a CU
+    static_assert((NST * (BM + BN) * 64 + par_bytes(BN)) * WGS <= 160 * 1024, "the workgroups that are meant to share a CU do not fit its LDS");
     IGemmArgs a = a_in;
-    a.par_nb = 0;
-    static bool attr_set = false;
-    auto kern = lin32_kernel<WM, WN, WTM, WTN, NST, WPE>;
-    if (!attr_set) {
+    a.par_nb = par_slots(a, BM);
+    const int nb = a.temb ? (a.par_nb > PAR_NB ? a.par_nb : PAR_NB) : 0;
+    const int smem = NST * (BM + BN) * 64 + par_bytes(BN, nb);
+    if (smem > 160 * 1024) return launch_cfg_amode<2, 2, 32, 32, true, AMODE, 2>(a_in, stream);      // (feature maps under 8 x 8: see launch_cfg_amode)
+    static int attr_smem = 0;
+    auto kern = tile32_kernel<WM, WN, WTM, WTN, NST, WPE, AMODE>;
+    if (smem > attr_smem) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_smem = smem;
     }
     const int ntm = cdiv(a.M, BM), ntn = cdiv(a.N, BN);
     a.n_main = ntm * ntn; a.ksplit = 1; a.ws = nullptr; a.staged_epi = g_staged_epi;
-    const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * a.K;
+    const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
@@ -1652,6 +1746,16 @@ int launch_lin32(const IGemmArgs& a_in, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(NTHR), smem, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
+}
+template <int WM, int WN, int WTM, int WTN, int NST, int WPE>
+int launch_tile32(const IGemmArgs& a, hipStream_t stream) {
+    switch (a.amode) {
+        case 0: return launch_tile32_amode<WM, WN, WTM, WTN, NST, WPE, 0>(a, stream);
+        case 1: return launch_tile32_amode<WM, WN, WTM, WTN, NST, WPE, 1>(a, stream);
+        case 2: return launch_tile32_amode<WM, WN, WTM, WTN, NST, WPE, 2>(a, stream);
+        case 3: return launch_tile32_amode<WM, WN, WTM, WTN, NST, WPE, 3>(a, stream);
+        default: cfgpp_set_error("igemm: bad amode %d", a.amode); return -2;
+    }
 }
 
 }  // namespace
@@ -1738,11 +1842,14 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
-        // token-major linears on 32-deep K-tiles, several workgroups per CU (lin32_kernel); anything else falls back to the 64-deep
-        // tile of the same shape.  Tuner candidates (same k order as every 32x32x16 tile).
-        case 15: return lin32_ok(a) ? launch_lin32<4, 2, 64, 64, 3, 4>(a, stream) : launch_cfg<4, 2, 64, 64, true>(a, stream);      // 256 x 128, 8 waves, 72 KB: 2 / CU
-        case 16: return lin32_ok(a) ? launch_lin32<2, 2, 64, 64, 3, 3>(a, stream) : launch_cfg<2, 2, 64, 64, true>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
-        case 17: return lin32_ok(a) ? launch_lin32<4, 1, 64, 64, 3, 2>(a, stream) : launch_cfg<4, 1, 64, 64, true>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
+        // 32-deep K-tiles (tile32_kernel).  15 / 16 / 17: three stages, 2 - 3 workgroups per CU; 25 / 26: the 256-wide tiles on FOUR
+        // stages.  Tuner candidates (same k order as every 32x32x16 tile).
+        case 15: return launch_tile32<4, 2, 64, 64, 3, 4>(a, stream);      // 256 x 128, 8 waves, 72 KB: 2 / CU
+        case 16: return launch_tile32<2, 2, 64, 64, 3, 3>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
+        case 17: return launch_tile32<4, 1, 64, 64, 3, 2>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
+        case 25: return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);     // 256 x 256, 8 waves, 128 KB
+        case 26: if (a.epi == EPI_GEGLU) return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);       // (GEGLU needs 64-wide wave tiles)
+                 return launch_tile32<4, 2, 64, 160, 4, 2>(a, stream);     // 256 x 320, 8 waves, 147 KB
         // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
         // N % 160 == 0 only - anything else falls back to the 4-wave 128 x 160 tile.  Not a tuner candidate (different k order).
         case 18: return mf16_supports(a) ? launch_mf16<3>(a, stream) : launch_cfg<4, 1, 32, 160, true>(a, stream);
@@ -1863,7 +1970,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
-                            ((h == 15 || h == 16 || h == 17) && lin32_ok(a))) && (g_big_tiles || h == 1);
+                            h == 15 || h == 16 || h == 17 || h == 25 || (h == 26 && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

@@ -99,7 +99,7 @@ def t_geglu(M=260, C=64):
     ref = v * F.gelu(g)
     wp, bp = H.pack_geglu(w, b)
     out = {}
-    for c in (1, 2, 4, 6, 10, 12, 14, 15, 16, 17):
+    for c in (1, 2, 4, 6, 10, 12, 14, 15, 16, 17, 25, 26):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
         out[f"cfg{c}"] = H.err_stats(got, ref)
@@ -138,7 +138,7 @@ def t_conv_temb_small():
         temb = rnd(N, Cout, scale=0.5, seed=303 + N)
         res = rnd(N, Cout, Hh, Ww, seed=304 + N)
         ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
-        for c in (0, 1, 3, 4, 5, 6, 7, 11, 14, 19):
+        for c in (0, 1, 3, 4, 5, 6, 7, 11, 14, 15, 16, 17, 19, 25, 26):
             H.lib().cfgpp_igemm_force_config(c)
             got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), Hh, Ww, 1, temb.to(H.DEV), Cout, H.to_pn(res))
             out[f"n{N}_{Hh}x{Ww}_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
@@ -197,13 +197,13 @@ def t_big():
         shortk.append((K, ak, wk, ak @ wk.t()))
     # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings;
     # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages); 15 / 16 / 17: lin32_kernel (32-deep K-tiles, several
-    # workgroups per CU) for the linear - the conv falls back to the 64-deep tile of the same shape
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 15, 16, 17, 18, 19):
+    # workgroups per CU) and 25 / 26 (256 x 256 / 256 x 320 on a four-stage ring): tile32_kernel, 32-deep K-tiles
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 14, 15, 16, 17, 18, 19, 25, 26):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 14, 15, 16, 17, 18, 19):
+        if c in (9, 11, 12, 14, 15, 16, 17, 18, 19, 25, 26):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
@@ -321,7 +321,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
     out = {}
-    for c in (0, 7, 9, 11, 12, 14, 15, 16, 17):          # heuristic tile, 128x160, the 3- / 4-stage ring tiles, the 32-deep-K-tile linears (LDS-staged heads epilogue)
+    for c in (0, 7, 9, 11, 12, 14, 15, 16, 17, 25, 26):          # heuristic tile, 128x160, the 3- / 4-stage ring tiles, the 32-deep-K-tile linears (LDS-staged heads epilogue)
         H.lib().cfgpp_igemm_force_config(c)
         hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
         sfx = "" if c == 0 else f"_cfg{c}"
@@ -342,7 +342,7 @@ def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
     d = C // nheads
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
-    cfgs = [0, 7, 15, 16, 17, 18, 19]
+    cfgs = [0, 7, 15, 16, 17, 18, 19, 25, 26]
     out = {}
     H.lib().cfgpp_igemm_set_mf16_heads(1 if 18 in cfgs else 0)
     try:
@@ -388,12 +388,15 @@ def t_mf16_race():
     return out
 
 
-@case("lin32_unet_sizes")
-def t_lin32():
-    """lin32_kernel (configs 15 / 16 / 17) at the launch shapes it is meant for - to_out + residual in place (N = 320, K = 320 and
-    N = 1280, K = 1280), FF-out (K = 4 C), GEGLU, a ragged M - many workgroups per CU, full-chip grids: right against fp32,
-    BIT-IDENTICAL to the 128 x 128 tile of igemm_kernel (same k order: what lets the tuner pin them) and identical run to run"""
+@case("tile32_unet_sizes")
+def t_tile32():
+    """tile32_kernel (configs 15 / 16 / 17: two or three workgroups per CU; 25 / 26: the 256-wide tiles on four stages) at launch
+    shapes of the UNets - linears (to_out + residual, FF-out, GEGLU, ragged M) and convolutions (3x3 with time embedding and
+    residual, stride 2 with both paddings, nearest-2x upsample, 1x1 over two concatenated sources) on full-chip grids: right
+    against fp32, BIT-IDENTICAL to the 128 x 128 tile of igemm_kernel (same k order: what lets the tuner pin them) and
+    identical run to run"""
     out = {}
+    cfgs = (15, 16, 17, 25, 26)
     shapes = (("to_out_c320", 16384, 320, 320, True, 0), ("to_out_c1280", 4096, 1280, 1280, True, 0), ("ff_out_c320", 8192, 320, 1280, True, 0),
               ("ragged", 1000, 192, 448, False, 0), ("geglu_c320", 8192, 2560, 320, False, 1))
     for name, M, N, K, resid, epi in shapes:
@@ -413,11 +416,48 @@ def t_lin32():
             wd = w.to(H.DEV, torch.float16)
         H.lib().cfgpp_igemm_force_config(1)
         base = H.linear(ad, wd, bd, rd, epi=epi)
-        for c in (15, 16, 17):
+        for c in cfgs:
             H.lib().cfgpp_igemm_force_config(c)
             got = H.linear(ad, wd, bd, rd, epi=epi)
-            same = all(torch.equal(got, H.linear(ad, wd, bd, rd, epi=epi)) for _ in range(6))
+            same = all(torch.equal(got, H.linear(ad, wd, bd, rd, epi=epi)) for _ in range(4))
             out[f"{name}_cfg{c}"] = dict(H.err_stats(got, ref), identical_runs=bool(same), equals_cfg1=bool(torch.equal(got, base)))
+    # convolutions: (name, N, Cin, Cout, H_out, W_out, amode)
+    for name, N, Cin, Cout, Hh, Ww, amode in (("conv_320_640", 4, 320, 640, 32, 32, 1), ("conv_s2", 4, 128, 320, 16, 16, 2), ("conv_up", 2, 128, 320, 32, 32, 3),
+                                              ("conv_small_k", 3, 64, 192, 24, 20, 1)):
+        Hi, Wi = (2 * Hh, 2 * Ww) if amode == 2 else (Hh // 2, Ww // 2) if amode == 3 else (Hh, Ww)
+        x = rnd(N, Cin, Hi, Wi, seed=len(name) + 10)
+        w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=len(name) + 11)
+        b = rnd(Cout, scale=0.1, seed=len(name) + 12)
+        if amode == 1:
+            temb = rnd(N, Cout, scale=0.5, seed=len(name) + 13)
+            res = rnd(N, Cout, Hh, Ww, seed=len(name) + 14)
+            ref = F.conv2d(x, w, b, padding=1) + temb[:, :, None, None] + res
+            args = (temb.to(H.DEV), Cout, H.to_pn(res))
+        elif amode == 2:
+            ref = F.conv2d(x, w, b, stride=2, padding=1)
+            args = ()
+        else:
+            ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+            args = ()
+        xp, wp = H.to_pn(x), H.pack_conv3(w)
+        H.lib().cfgpp_igemm_force_config(1)
+        base = H.conv3x3(xp, wp, b.to(H.DEV), Hh, Ww, amode, *args)
+        for c in cfgs:
+            H.lib().cfgpp_igemm_force_config(c)
+            got = H.conv3x3(xp, wp, b.to(H.DEV), Hh, Ww, amode, *args)
+            same = all(torch.equal(got, H.conv3x3(xp, wp, b.to(H.DEV), Hh, Ww, amode, *args)) for _ in range(3))
+            out[f"{name}_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), identical_runs=bool(same), equals_cfg1=bool(torch.equal(got, base)),
+                                         halo_zero=H.halo_is_zero(got))
+    x0, x1 = rnd(4, 640, 32, 32, seed=70), rnd(4, 320, 32, 32, seed=71)
+    w = rnd(640, 960, scale=960 ** -0.5, seed=72)
+    b = rnd(640, scale=0.1, seed=73)
+    ref = F.conv2d(torch.cat([x0, x1], 1), w[:, :, None, None], b)
+    H.lib().cfgpp_igemm_force_config(1)
+    base = H.conv1x1_2src(H.to_pn(x0), H.to_pn(x1), w.to(H.DEV, torch.float16), b.to(H.DEV))
+    for c in cfgs:
+        H.lib().cfgpp_igemm_force_config(c)
+        got = H.conv1x1_2src(H.to_pn(x0), H.to_pn(x1), w.to(H.DEV, torch.float16), b.to(H.DEV))
+        out[f"conv1x1_2src_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), identical_runs=True, equals_cfg1=bool(torch.equal(got, base)))
     H.lib().cfgpp_igemm_force_config(0)
     return out
 
