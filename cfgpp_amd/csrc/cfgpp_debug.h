@@ -77,7 +77,8 @@ int cfgpp_op_igemm_heads(const void* a, int K, const void* w, int M, int N, cons
                          int q_tok_pad, int tok_pad, void* stream);
 /* 0 = heuristic, 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 256x256, 5 = 256x320, 6 = 256x128, 7 = 128x160, 8 = 128x320,
  * 10 = 256x320 (waves along M); 9 / 11 = 128x160 on a 3- / 4-stage LDS ring, 12 = 128x128 and 14 = 256x128 on 3 stages;
- * 15 / 16 / 17 = 256x128 (8 waves) / 128x128 / 256x64 (4 waves) on 32-deep K-tiles, 2 - 3 workgroups per CU (token-major linears);
+ * 15 / 16 / 17 = 256x128 (8 waves) / 128x128 / 256x64 (4 waves) on 32-deep K-tiles and three stages, 2 - 3 workgroups per CU;
+ * 13 / 20 = 256x256 / 256x320 on 32-deep K-tiles and FOUR stages (tile32_kernel);
  * 18 / 19 = 128x160 as 8 waves of 32x80 on the 16x16x32 MFMA, 3 / 4 stages (plain-store launches with N % 160 == 0);
  * 21..23 = register-staged 1..3 */
 void cfgpp_igemm_force_config(int cfg);

@@ -972,7 +972,7 @@ igemm_reduce_kernel(const IGemmArgs p) {
 // they fit) and one workgroup per CU.  Here a K-tile is 32 deep - LDS rows of 64 bytes, (BM + BN) * 64 bytes per
 // stage - which buys, for the same LDS:
 //   * 256 x 256 / 256 x 320 on a FOUR-stage ring (128 / 147 KB): three half-tiles of lookahead, requested and awaited at twice
-//     the granularity (configs 25 / 26);
+//     the granularity (configs 13 / 20);
 //   * 256 x 128 (8 waves, 72 KB), 128 x 128 and 256 x 64 (4 waves, 48 / 60 KB) on three stages with TWO or THREE workgroups per
 //     CU (configs 15 / 16 / 17): one workgroup's prologue / epilogue runs under another's MFMAs and the chip's store bursts
 //     de-synchronise - what the K <= 1280 projections of the transformer blocks lacked (round-3 timelines: a workgroup is
@@ -1842,13 +1842,14 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         // (value | gate) column pairs, so the GEGLU projections (N = 8C = k * 320) can use the 320-wide tile too.
         // Pinned by the tuner for GEGLU launches only (a plain store would not fit its LDS-staged epilogue).
         case 10: return launch_cfg<8, 1, 32, 320, true>(a, stream);
-        // 32-deep K-tiles (tile32_kernel).  15 / 16 / 17: three stages, 2 - 3 workgroups per CU; 25 / 26: the 256-wide tiles on FOUR
-        // stages.  Tuner candidates (same k order as every 32x32x16 tile).
+        // 32-deep K-tiles (tile32_kernel).  15 / 16 / 17: three stages, 2 - 3 workgroups per CU; 13 / 20: the 256-wide tiles on FOUR
+        // stages.  Tuner candidates (same k order as every 32x32x16 tile).  (Numbers above 20 mean "register-staged variant of
+        // config - 20", see above.)
         case 15: return launch_tile32<4, 2, 64, 64, 3, 4>(a, stream);      // 256 x 128, 8 waves, 72 KB: 2 / CU
         case 16: return launch_tile32<2, 2, 64, 64, 3, 3>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
         case 17: return launch_tile32<4, 1, 64, 64, 3, 2>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
-        case 25: return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);     // 256 x 256, 8 waves, 128 KB
-        case 26: if (a.epi == EPI_GEGLU) return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);       // (GEGLU needs 64-wide wave tiles)
+        case 13: return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);     // 256 x 256, 8 waves, 128 KB
+        case 20: if (a.epi == EPI_GEGLU) return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);       // (GEGLU needs 64-wide wave tiles)
                  return launch_tile32<4, 2, 64, 160, 4, 2>(a, stream);     // 256 x 320, 8 waves, 147 KB
         // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
         // N % 160 == 0 only - anything else falls back to the 4-wave 128 x 160 tile.  Not a tuner candidate (different k order).
@@ -1970,7 +1971,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
-                            h == 15 || h == 16 || h == 17 || h == 25 || (h == 26 && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
+                            h == 13 || h == 15 || h == 16 || h == 17 || (h == 20 && a.epi != EPI_GEGLU)) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

@@ -77,9 +77,9 @@ def test_vt_key_permutation():
             assert p == list(range(p[0], p[0] + 8)) and p[0] % 8 == 0, (tt, hi, p)
 
 
-# ---- round 4: 64-byte rows (32-deep K-tiles of lin32_kernel), the conv_out halo tile ----
+# ---- round 4: 64-byte rows (32-deep K-tiles of tile32_kernel), the conv_out halo tile ----
 def test_64_byte_rows_fragment_reads_and_dma_swizzle():
-    """lin32_kernel: rows of 64 bytes (4 chunks), physical = logical ^ ((row >> 2) & 3); a
+    """tile32_kernel: rows of 64 bytes (4 chunks), physical = logical ^ ((row >> 2) & 3); a
     fragment read is row = base + (lane & 31), logical chunk 2 * ks + (lane >> 5), ks = 0, 1; the DMA piece is 16 rows, lane ->
     (row = lane >> 2, physical slot = lane & 3) loading source chunk slot ^ ((row >> 2) & 3)"""
     for base in range(0, 384, 32):
