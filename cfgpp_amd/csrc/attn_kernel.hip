@@ -282,8 +282,8 @@ attn_kernel(const AttnArgs a) {
 // K tile  : LDS [64 keys  ][64 halfs], row = key,   16-B chunk c = 8 head dims
 // V^T tile: LDS [64 d-rows][64 keys ], row = d,     16-B chunk c = 8 (permuted) keys
 // physical chunk = logical chunk ^ ((row >> 1) & 7); one DMA piece = 8 rows x 128 B = 64 lanes x 16 B.
-template <int D16, bool ONES, int NST>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU)
-__global__ void __launch_bounds__(256)
+template <int D16, bool ONES, int NST, int WPE = 3>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU); WPE = waves per SIMD the
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      // register allocation targets (4: <= 128 VGPRs, with NST = 2 four workgroups / CU)
 attn64_kernel(const AttnArgs a) {
     constexpr int DP = 64, DT = 2;
     constexpr int TILE = 64 * 128;               // bytes of one K or V^T tile
@@ -371,7 +371,20 @@ attn64_kernel(const AttnArgs a) {
 
         // ---- S^T - m = K Q^T + (-m) for two 32-key sub-tiles (log2 domain) ----
         f32x16 s[2];
-        {
+        if constexpr (WPE >= 4) {
+            // register-lean form (<= 128 VGPRs: four waves per SIMD): one 32-key sub-tile's K fragments at a time; the other waves of
+            // the SIMD cover the LDS latency
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                half8_t kf1[D16];
+#pragma unroll
+                for (int ks = 0; ks < D16; ++ks)
+                    kf1[ks] = *reinterpret_cast<const half8_t*>(Ks + kt * 32 * 128 + frow + ((((ks << 1) | hi) ^ fsw) << 4));
+#pragma unroll
+                for (int ks = 0; ks < D16; ++ks)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[ks], qf[ks], ks == 0 ? negm : s[kt], 0, 0, 0);
+            }
+        } else {
             half8_t kf[2][D16];                  // all K fragments of the tile in flight before the first MFMA
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -637,11 +650,11 @@ xattn64_kernel(const AttnArgs a, int xqb /* 128-query blocks per workgroup */, i
     }
 }
 
-template <int D16, bool ONES, int NST>
+template <int D16, bool ONES, int NST, int WPE = 3>
 int launch_attn64(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int smem = NST * 2 * 64 * 128;
     static bool attr_set = false;
-    auto kern = attn64_kernel<D16, ONES, NST>;
+    auto kern = attn64_kernel<D16, ONES, NST, WPE>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -677,12 +690,14 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch).  (A software-pipelined form
                                  // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
                                  // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
+static int g_attn_occ = 3;       // attn64_kernel: 3 = three workgroups per CU on a 3-stage ring (default), 4 = four on a 2-stage ring with <= 128 VGPRs (A/B)
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
 
 void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
+void cfgpp_attention_set_occupancy(int waves_per_simd) { g_attn_occ = waves_per_simd == 4 ? 4 : 3; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
 
@@ -740,7 +755,10 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     }
     if (dt == 2 && g_attn_dma) {                   // dp = 64 (d = 40, 48, 56, 64): LDS-DMA kernel
         int rc;        // (a 2-stage ring was measured within 1 % of the 3-stage one and is not built)
-        if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
+        if (g_attn_occ == 4) {                      // A/B: four workgroups per CU (two-stage ring, <= 128 VGPRs)
+            if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
+            else rc = ones ? launch_attn64<4, true, 2, 4>(a, grid, s) : launch_attn64<4, false, 2, 4>(a, grid, s);
+        } else if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
         else rc = ones ? launch_attn64<4, true, 3>(a, grid, s) : launch_attn64<4, false, 3>(a, grid, s);
         if (rc) return -1;
         CFGPP_HIP_CHECK(hipGetLastError());
