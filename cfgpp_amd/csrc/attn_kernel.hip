@@ -304,22 +304,26 @@ attn64_kernel(const AttnArgs a) {
     // DMA source addressing: lane -> (row r8 = lane >> 3 of the piece, physical chunk pc = lane & 7); the wave's
     // pieces are K rows [16 * wid, 16 * wid + 16) and V^T rows [16 * wid, 16 * wid + 16) of the tile
     const int r8 = lane >> 3, pc = lane & 7;
-    const half_t* ksrc[2]; const half_t* vsrc[2];
+    // (32-bit element offsets from the wave-uniform bases Kb / Vb: half the registers of per-lane 64-bit pointers, and the loads can
+    // take the scalar-base + vector-offset form)
+    int koff[2], voff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int row = wid * 16 + h * 8 + r8;
         const int lc = pc ^ ((row >> 1) & 7);
-        ksrc[h] = Kb + (long)row * DP + lc * 8;                    // + t * 64 * DP per tile
-        vsrc[h] = Vb + (long)row * a.k_tok_pad + lc * 8;           // + t * 64 per tile
+        koff[h] = row * DP + lc * 8;                               // + t * 64 * DP per tile
+        voff[h] = row * a.k_tok_pad + lc * 8;                      // + t * 64 per tile
     }
     auto dma_tile = [&](int t, int stage) {
         char* Ks = smem + stage * STAGE;
         char* Vs = Ks + TILE;
+        const half_t* Kt = Kb + (long)t * 64 * DP;                 // (wave-uniform)
+        const half_t* Vt = Vb + (long)t * 64;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[h] + (long)t * 64 * DP),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + koff[h]),
                                              (__attribute__((address_space(3))) void*)(Ks + (wid * 16 + h * 8) * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[h] + (long)t * 64),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + voff[h]),
                                              (__attribute__((address_space(3))) void*)(Vs + (wid * 16 + h * 8) * 128), 16, 0, 0);
         }
     };
@@ -376,13 +380,17 @@ attn64_kernel(const AttnArgs a) {
             // the SIMD cover the LDS latency
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                half8_t kf1[D16];
 #pragma unroll
-                for (int ks = 0; ks < D16; ++ks)
-                    kf1[ks] = *reinterpret_cast<const half8_t*>(Ks + kt * 32 * 128 + frow + ((((ks << 1) | hi) ^ fsw) << 4));
+                for (int k0 = 0; k0 < D16; k0 += 2) {    // two fragments (8 registers) in flight at a time
+                    half8_t kf1[2];
 #pragma unroll
-                for (int ks = 0; ks < D16; ++ks)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[ks], qf[ks], ks == 0 ? negm : s[kt], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u)
+                        if (k0 + u < D16) kf1[u] = *reinterpret_cast<const half8_t*>(Ks + kt * 32 * 128 + frow + (((((k0 + u) << 1) | hi) ^ fsw) << 4));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (k0 + u < D16) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1[u], qf[k0 + u], k0 + u == 0 ? negm : s[kt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // later fragments are not hoisted above these MFMAs (registers)
+                }
             }
         } else {
             half8_t kf[2][D16];                  // all K fragments of the tile in flight before the first MFMA
@@ -459,18 +467,23 @@ attn64_kernel(const AttnArgs a) {
     }
 
     // ---- finalize: O = O^T / l, store token-major ----
+    // (lane-derived indices are re-derived here from an opaque copy of the lane id: kept live across the key loop they are what
+    //  the register-lean instantiations spilled)
+    int lane_f = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_f));
+    const int l31_f = lane_f & 31, hi_f = lane_f >> 5;
     float l_tot;
     if constexpr (ONES) {
         const int dr = a.d & 31;
         float lv = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) if (dr == 8 * g) lv = oacc[DT - 1][4 * g];
-        l_tot = __shfl(lv, l31);
+        l_tot = __shfl(lv, l31_f);
     } else {
         l_tot = l_run + __shfl_xor(l_run, 32);
     }
     const float inv_l = 1.0f / l_tot;
-    const int q = q0 + l31;
+    const int q = qb * 128 + wid * 32 + l31_f;
     if (q < a.nq) {
         const int b = bh / a.heads, head = bh - b * a.heads;
         half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
@@ -478,7 +491,7 @@ attn64_kernel(const AttnArgs a) {
         for (int i = 0; i < DT; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int dd = i * 32 + 8 * g + 4 * hi;
+                const int dd = i * 32 + 8 * g + 4 * hi_f;
                 if (dd < a.d) {
                     half4_t o;
 #pragma unroll
@@ -690,14 +703,17 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch).  (A software-pipelined form
                                  // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
                                  // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
-static int g_attn_occ = 3;       // attn64_kernel: 3 = three workgroups per CU on a 3-stage ring (default), 4 = four on a 2-stage ring with <= 128 VGPRs (A/B)
+static int g_attn_occ = 4;       // attn64_kernel: 4 (default) = four workgroups per CU - 2-stage ring (32 KB), register-lean K-fragment loads, <= 128
+                                 // VGPRs - so that four waves per SIMD interleave their QK^T / softmax / PV phases; 3 = three workgroups on a 3-stage ring
+                                 // (rounds 2-3).  Same arithmetic, bit-identical results.  profiles/r04/ab/attention_occupancy_call9.txt: d = 40
+                                 // N = 4096 515 -> 485 us, SDXL d = 64 N = 4096 225 -> 206 us; forwards 18.99 -> 18.79 ms / 36.40 -> 36.20 ms
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
 
 void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
-void cfgpp_attention_set_occupancy(int waves_per_simd) { g_attn_occ = waves_per_simd == 4 ? 4 : 3; }
+void cfgpp_attention_set_occupancy(int waves_per_simd) { g_attn_occ = waves_per_simd == 3 ? 3 : 4; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
 

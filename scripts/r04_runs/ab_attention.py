@@ -29,4 +29,4 @@ for (B, h, N, d, what) in ((16, 8, 4096, 40, "SD1.5 64x64 level, 16 rows"), (4, 
         us = e0.elapsed_time(e1) / 20 * 1e3
         line += f" | occ {occ}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s rel {err:.1e}"
     print(line, flush=True)
-H.lib().cfgpp_attention_set_occupancy(3)
+H.lib().cfgpp_attention_set_occupancy(4)

@@ -43,7 +43,7 @@ ref = None
 for vn, kv in variants:
     lib.cfgpp_igemm_set_tune_mask(int(kv.get("mask", "0xffffffff"), 0))
     lib.cfgpp_igemm_set_mf16_linear(int(kv.get("mf16lin", "1")))
-    lib.cfgpp_attention_set_occupancy(int(kv.get("attnocc", "3")))
+    lib.cfgpp_attention_set_occupancy(int(kv.get("attnocc", "4")))
     t0 = time.time()
     eng = HipEngine(cfg, max_batch=B, weights=sd)
     eng.set_context(uc, c, te, ti)
