@@ -114,7 +114,6 @@ DEBUG_PROTOTYPES = {
     "cfgpp_groupnorm_set_mode": (None, [_I]),
     "cfgpp_layernorm_set_rows_per_wave": (None, [_I]),
     "cfgpp_attention_set_dma": (None, [_I]),
-    "cfgpp_attention_set_occupancy": (None, [_I]),
     "cfgpp_attention_set_stagger": (None, [_I]),
     "cfgpp_attention_set_cross": (None, [_I]),
 }

@@ -375,7 +375,7 @@ attn64_kernel(const AttnArgs a) {
 
         // ---- S^T - m = K Q^T + (-m) for two 32-key sub-tiles (log2 domain) ----
         f32x16 s[2];
-        if constexpr (WPE >= 4) {
+        {
             // register-lean form (<= 128 VGPRs: four waves per SIMD): one 32-key sub-tile's K fragments at a time; the other waves of
             // the SIMD cover the LDS latency
 #pragma unroll
@@ -392,19 +392,6 @@ attn64_kernel(const AttnArgs a) {
                     __builtin_amdgcn_sched_barrier(0);   // later fragments are not hoisted above these MFMAs (registers)
                 }
             }
-        } else {
-            half8_t kf[2][D16];                  // all K fragments of the tile in flight before the first MFMA
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int ks = 0; ks < D16; ++ks)
-                    kf[kt][ks] = *reinterpret_cast<const half8_t*>(Ks + kt * 32 * 128 + frow + ((((ks << 1) | hi) ^ fsw) << 4));
-            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs (the scheduler would re-serialise them)
-#pragma unroll
-            for (int ks = 0; ks < D16; ++ks)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? negm : s[kt], 0, 0, 0);
         }
         if (tail != 0 && t == ntiles - 1) {      // wave-uniform: mask keys >= nk_valid (cross-attention, 77 keys)
             const int kbase = t * 64 + 4 * hi;
@@ -703,17 +690,12 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch).  (A software-pipelined form
                                  // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
                                  // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
-static int g_attn_occ = 4;       // attn64_kernel: 4 (default) = four workgroups per CU - 2-stage ring (32 KB), register-lean K-fragment loads, <= 128
-                                 // VGPRs - so that four waves per SIMD interleave their QK^T / softmax / PV phases; 3 = three workgroups on a 3-stage ring
-                                 // (rounds 2-3).  Same arithmetic, bit-identical results.  profiles/r04/ab/attention_occupancy_call9.txt: d = 40
-                                 // N = 4096 515 -> 485 us, SDXL d = 64 N = 4096 225 -> 206 us; forwards 18.99 -> 18.79 ms / 36.40 -> 36.20 ms
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
 
 void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
-void cfgpp_attention_set_occupancy(int waves_per_simd) { g_attn_occ = waves_per_simd == 3 ? 3 : 4; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
 
@@ -771,11 +753,10 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     }
     if (dt == 2 && g_attn_dma) {                   // dp = 64 (d = 40, 48, 56, 64): LDS-DMA kernel
         int rc;        // (a 2-stage ring was measured within 1 % of the 3-stage one and is not built)
-        if (g_attn_occ == 4) {                      // A/B: four workgroups per CU (two-stage ring, <= 128 VGPRs)
-            if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
-            else rc = ones ? launch_attn64<4, true, 2, 4>(a, grid, s) : launch_attn64<4, false, 2, 4>(a, grid, s);
-        } else if (d16 == 3) rc = launch_attn64<3, true, 3>(a, grid, s);
-        else rc = ones ? launch_attn64<4, true, 3>(a, grid, s) : launch_attn64<4, false, 3>(a, grid, s);
+        // four workgroups per CU: two-stage ring (32 KB), <= 128 VGPRs (the three-per-CU form on a 3-stage ring of rounds 2-3 measured
+        // 3 - 9 % slower alone and 0.3 - 1 % per forward, profiles/r04/ab/attention_occupancy_call9.txt / _call10.txt)
+        if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
+        else rc = ones ? launch_attn64<4, true, 2, 4>(a, grid, s) : launch_attn64<4, false, 2, 4>(a, grid, s);
         if (rc) return -1;
         CFGPP_HIP_CHECK(hipGetLastError());
         return 0;

@@ -37,9 +37,6 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
                        int nq, int nk, int q_tok_pad, int k_tok_pad, void* stream);
 /* A/B switch for head dims padded to 64: 1 (default) the LDS-DMA kernel, 0 the register-staged kernel */
 void cfgpp_attention_set_dma(int mode);
-/* A/B switch of the LDS-DMA attention kernel: 4 (default) = four workgroups per CU (2-stage ring, register-lean K-fragment
- * loads, <= 128 VGPRs), 3 = three workgroups per CU on a 3-stage ring; bit-identical results */
-void cfgpp_attention_set_occupancy(int waves_per_simd);
 /* A/B knob of the LDS-DMA attention kernel: the workgroups sharing a CU start `sleeps` x 64 cycles apart per dispatch slot
  * (0 = together, the default) so that their QK^T / softmax / PV phases interleave instead of coinciding */
 void cfgpp_attention_set_stagger(int sleeps);

@@ -1,5 +1,7 @@
-"""Attention kernel alone, hot caches: three vs four workgroups per CU (cfgpp_attention_set_occupancy) at the UNets' self-attention
-shapes; correctness of both against torch SDPA in fp32."""
+"""Attention kernel alone, hot caches, at the UNets' self-attention shapes; correctness against torch SDPA in fp32.  Calls 9 / 10 of
+round 4 ran it on the builds that still carried both forms (three workgroups per CU on a 3-stage ring vs four on a 2-stage ring,
+switch cfgpp_attention_set_occupancy; profiles/r04/ab/attention_occupancy_call9.txt, _call10.txt); on a build without the switch it
+times the shipped form twice per "occ" column."""
 import os, sys, torch
 import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +18,10 @@ for (B, h, N, d, what) in ((16, 8, 4096, 40, "SD1.5 64x64 level, 16 rows"), (4, 
     flops = 4.0 * B * h * N * N * d
     line = f"{what}: B*heads={B * h} N={N} d={d}"
     for occ in (3, 4, 3, 4):
-        H.lib().cfgpp_attention_set_occupancy(occ)
+        try:
+            H.lib().cfgpp_attention_set_occupancy(occ)
+        except AttributeError:
+            pass
         out = H.attention(hq, hk, hvt, B, h, d, N, N, qp, kp)
         err = float((out[:2].float().cpu() - ref).norm() / ref.norm()) if ref is not None else float("nan")
         for _ in range(3):
@@ -29,4 +34,7 @@ for (B, h, N, d, what) in ((16, 8, 4096, 40, "SD1.5 64x64 level, 16 rows"), (4, 
         us = e0.elapsed_time(e1) / 20 * 1e3
         line += f" | occ {occ}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s rel {err:.1e}"
     print(line, flush=True)
-H.lib().cfgpp_attention_set_occupancy(4)
+try:
+    H.lib().cfgpp_attention_set_occupancy(4)
+except AttributeError:
+    pass

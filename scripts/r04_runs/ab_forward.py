@@ -1,7 +1,6 @@
 """Same-box, same-process A/B of whole UNet forwards:
     python scripts/r04_runs/ab_forward.py sd15 8 "base:mask=0xffff7fff;lin32:mask=0xffffffff;lin32_nomf16lin:mask=0xffffffff,mf16lin=0"
-variant = name:key=value,...  keys: mask (tuner candidate mask, bit c = tile config c), mf16lin (16x16x32 rule takes linears),
-attnocc (3 / 4 workgroups per CU of the LDS-DMA attention kernel).
+variant = name:key=value,...  keys: mask (tuner candidate mask, bit c = tile config c), mf16lin (16x16x32 rule takes linears).
 The synthetic state dict is generated once; every variant builds its own engine from it, tunes, and is timed as back-to-back
 predict() calls (3 x 20 forwards: min and median) - the number the sampling loop sees - plus the per-family sums and the pinned
 tile histogram of a profiled forward; `--table` prints the per-launch table of the LAST variant."""
@@ -43,7 +42,6 @@ ref = None
 for vn, kv in variants:
     lib.cfgpp_igemm_set_tune_mask(int(kv.get("mask", "0xffffffff"), 0))
     lib.cfgpp_igemm_set_mf16_linear(int(kv.get("mf16lin", "1")))
-    lib.cfgpp_attention_set_occupancy(int(kv.get("attnocc", "4")))
     t0 = time.time()
     eng = HipEngine(cfg, max_batch=B, weights=sd)
     eng.set_context(uc, c, te, ti)
