@@ -29,7 +29,7 @@
 //     (global_load_lds_dwordx4: no VGPR staging, no ds_write pass - the VGPR -> LDS store path was what
 //     saturated the CU's LDS pipe: PMC showed 33 % of the LDS cycles as bank conflicts of the old 2 x
 //     ds_read_b64 V reads and 47 % of the wave time parked) into unpadded rows with the igemm's XOR swizzle
-//     applied to the per-lane SOURCE chunk, on a 3-stage ring: a tile has two tile times to land, one
+//     applied to the per-lane SOURCE chunk, on a 2-stage ring (32 KB: FOUR workgroups per CU since round 4; rounds 2-3: 3 stages, three), one
 //     raw s_barrier per tile, counted vmcnt.
 //   * other head dims (80, 160): attn_kernel, register-staged double buffering, padded LDS rows.
 // Cross-attention (77 keys padded to 128) uses the same kernel with nk_valid = 77.
@@ -282,7 +282,7 @@ attn_kernel(const AttnArgs a) {
 // K tile  : LDS [64 keys  ][64 halfs], row = key,   16-B chunk c = 8 head dims
 // V^T tile: LDS [64 d-rows][64 keys ], row = d,     16-B chunk c = 8 (permuted) keys
 // physical chunk = logical chunk ^ ((row >> 1) & 7); one DMA piece = 8 rows x 128 B = 64 lanes x 16 B.
-template <int D16, bool ONES, int NST, int WPE = 3>        // NST = LDS ring stages (3: 48 KB, 3 workgroups / CU); WPE = waves per SIMD the
+template <int D16, bool ONES, int NST, int WPE = 3>        // NST = LDS ring stages (shipped: 2 = 32 KB); WPE = waves per SIMD the
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      // register allocation targets (4: <= 128 VGPRs, with NST = 2 four workgroups / CU)
 attn64_kernel(const AttnArgs a) {
     constexpr int DP = 64, DT = 2;
@@ -687,7 +687,7 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel (3-stage ring), 0 = register-staged kernel (A/B switch).  (A software-pipelined form
+static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel, 0 = register-staged kernel (A/B switch).  (A software-pipelined form
                                  // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
                                  // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
