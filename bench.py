@@ -172,7 +172,7 @@ def roofline_block(eng, config, B, dev, rnd):
     bytes per igemm launch, FETCH_SIZE x2 + WRITE_SIZE per the gfx950 note of the guide) and `mfma_util`
     (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)) of the igemm and attention kernels."""
     import re
-    # whole UNet forward at the job's batch (all lanes, as the sampling loop runs it): wall time of back-to-back predict() calls
+    # whole UNet forward at the job's batch, as the sampling loop runs it: wall time of back-to-back predict() calls
     zf = torch.randn((B, 4, eng.H, eng.W), device=dev)
     for _ in range(2):
         eng.predict(zf, 500.0)
