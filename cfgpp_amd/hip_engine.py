@@ -107,4 +107,4 @@ class HipEngine:
         return torch.randn_like(x)
 
     def flops_per_forward(self, rows: int) -> float:
-        return self.unet.flops(rows)          # (linear in rows: the lane split does not change the algorithmic work)
+        return self.unet.flops(rows)
