@@ -8,7 +8,8 @@
 
 #define OPS(X) X(0, "v_exp_f32 %0, %0") X(1, "v_exp_f16 %0, %0") X(2, "v_fma_f32 %0, %0, %0, %0") X(3, "v_pk_fma_f32 %0, %0, %0, %0") \
                X(4, "v_pk_fma_f16 %0, %0, %0, %0") X(5, "v_rcp_f32 %0, %0") X(6, "v_cvt_pkrtz_f16_f32 %0, %0, %0") X(7, "v_max_f32 %0, %0, %0") \
-               X(8, "v_pk_mul_f32 %0, %0, %0") X(9, "v_log_f32 %0, %0") X(10, "v_exp_f32 %0, %0\n v_fma_f32 %1, %1, %1, %1") X(11, "v_mov_b32 %0, %0")
+               X(8, "v_pk_mul_f32 %0, %0, %0") X(9, "v_log_f32 %0, %0") X(10, "v_exp_f32 %0, %0\n v_fma_f32 %1, %1, %1, %1") X(11, "v_mov_b32 %0, %0") \
+               X(12, "v_max3_f32 %0, %0, %0, %0") X(13, "v_cvt_pk_f16_f32 %0, %0, %0") X(14, "v_pk_max_f16 %0, %0, %0") X(15, "v_pk_mul_f16 %0, %0, %0")
 
 template <int OP>
 __global__ void k(unsigned long long* cyc, float* sink, int iters) {
@@ -38,7 +39,7 @@ int main() {
     unsigned long long* d; float* sink;
     hipMalloc(&d, 64 * 8); hipMalloc(&sink, 4096 * 4);
     const int iters = 2000;
-    const char* names[12];
+    const char* names[16];
 #define X(N, S) names[N] = S;
     OPS(X)
 #undef X
