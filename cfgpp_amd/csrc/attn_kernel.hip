@@ -36,8 +36,6 @@
 // softmax statistics and accumulation are fp32; P is rounded to fp16 for the PV
 // product (same as the reference's SDPA flash path under fp16 autocast).
 #include "common.h"
-#include <type_traits>
-#include <utility>
 
 namespace {
 
@@ -491,332 +489,6 @@ attn64_kernel(const AttnArgs a) {
     }
 }
 
-// ---- dp = 64, long key axis: the WOVEN form -----------------------------------------------------------------------------
-// attn64_kernel's key-tile step is a dependency chain inside every wave - QK^T MFMAs -> max -> 32 exponentials -> packs -> PV
-// MFMAs - so the matrix pipe and the VALU only overlap ACROSS waves.  Measured on one CU with no memory at all
-// (scripts/r04_runs/micro_overlap.hip, profiles/r04/micro_overlap_mfma_valu.txt): that chain tops out at 0.66 matrix-pipe
-// utilisation with four waves per SIMD (the flash loop reaches 0.46-0.48 with LDS, barriers and DMA on top), a two-tile
-// software pipeline at 0.72 with two waves (round 3's attempt: slower in practice), but the same instruction mix with the VALU
-// work INDEPENDENT of the MFMAs it sits between runs at 0.90 with two waves per SIMD.  This kernel presents exactly that to the
-// issue logic: step t issues the QK^T MFMAs of tile t+1 and the PV MFMAs of tile t-1, and between every two of them a slice of
-// tile t's softmax (exponentials of S(t), packs into P(t), the running-max scan of S(t+1)):
-//     slot  0 .. 2*D16-1 : S(t+1) = K(t+1) Q^T - m_ref     + 3 (d = 64) or 4 (d = 40) exponentials of S(t) each
-//     slot  2*D16 .. +7  : O += V^T(t-1) P(t-1)            + the last 8 exponentials, 16 v_max3 over S(t+1), the packs of P(t)
-//                                                            (fragment f of P(t) is packed into the registers of P(t-1)'s
-//                                                            fragment f two slots after the MFMAs that consumed it)
-// Three score tiles are live (S(t+1) accumulating, S(t) being exponentiated, P(t-1)/P(t) packed): ~200 VGPRs, two waves per
-// SIMD, two workgroups per CU.  K and V^T have separate 4-stage LDS rings (64 KB per workgroup) because they are consumed two
-// steps apart: step t issues the DMA of K(t+4) and V^T(t+2), both three steps ahead of their use, into the stages of K(t) and
-// V^T(t-2), whose last readers finished before this step's barrier.  The step body is instantiated per t % 4: the S(t) /
-// S(t+1) register sets swap roles every step (no 32-register moves) and every LDS read is `ds_read_b128 v, v_off[c] offset:imm`
-// with the ring stage in the immediate - four per-lane offsets computed once, no address arithmetic in the loop; the reads are
-// issued two slots ahead of their MFMA with counted lgkmcnt waits (inline asm: the compiler's own waits were lgkmcnt(0)).
-// Re-referencing (rare after tile 0, see RESCALE_THR) happens at the END of a step, when S(t+1)'s maximum is known: O (tiles
-// <= t-1) and the not-yet-accumulated P(t) are scaled by 2^-delta with delta rounded UP to an integer, so the scaling of the
-// fp16 P(t) is exact.  Requires nk_valid % 64 == 0 and at least 4 key tiles (the launcher falls back to attn64_kernel otherwise).
-// DIAG (timing experiments only, results are wrong): 1 = no DMA / vmcnt waits, 2 = no barriers, 4 = no LDS reads, 8 = no softmax VALU
-template <int D16, bool ONES, int DIAG = 0, int LA = 2>      // LA: slots an LDS fragment read is issued ahead of its MFMA
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-attn64w_kernel(const AttnArgs a) {
-    constexpr int DP = 64, DT = 2;
-    constexpr int TILE = 64 * 128;               // bytes of one K or V^T tile
-    constexpr int NQK = 2 * D16, NPV = 8;        // MFMAs of one tile's QK^T / PV
-    constexpr int EPQ = 24 / NQK;                // exponentials woven after each QK^T MFMA (3 or 4); the other 8 go after PV MFMAs 0-3
-    static_assert(EPQ * NQK == 24, "24 exponentials are spread over the QK^T slots");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K ring [4][TILE] | V^T ring [4][TILE]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    int qb, bh;
-    attn_block_map(a.nqb, qb, bh);
-    const int q0 = qb * 128 + wid * 32;
-    const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
-    const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
-    const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
-
-    // DMA source addressing as in attn64_kernel: two 8-row pieces of K and two of V^T per wave and tile; unsigned 32-bit element
-    // offsets from the wave-uniform tile bases (scalar base + vector offset form of the load)
-    const int r8 = lane >> 3, pc = lane & 7;
-    unsigned koff[2], voff[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int row = wid * 16 + h * 8 + r8;
-        const int lc = pc ^ ((row >> 1) & 7);
-        koff[h] = (unsigned)(row * DP + lc * 8);
-        voff[h] = (unsigned)(row * a.k_tok_pad + lc * 8);
-    }
-    auto dma_k = [&](int t, int stage) {
-        if constexpr (DIAG & 1) return;
-        const half_t* Kt = Kb + (long)t * 64 * DP;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + koff[h]),
-                                             (__attribute__((address_space(3))) void*)(smem + stage * TILE + (wid * 16 + h * 8) * 128), 16, 0, 0);
-    };
-    auto dma_v = [&](int t, int stage) {
-        if constexpr (DIAG & 1) return;
-        const half_t* Vt = Vb + (long)t * 64;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + voff[h]),
-                                             (__attribute__((address_space(3))) void*)(smem + (4 + stage) * TILE + (wid * 16 + h * 8) * 128), 16, 0, 0);
-    };
-
-    const int ntiles = a.nk_valid >> 6;          // (>= 4, no partial tile: launcher)
-    dma_k(0, 0);
-    half8_t qf[D16];                             // Q^T fragments (B operand), pre-multiplied by d^-1/2 * log2(e)
-#pragma unroll
-    for (int ks = 0; ks < D16; ++ks) {
-        const half8_t raw = *reinterpret_cast<const half8_t*>(Qb + (long)(q0 + l31) * DP + ks * 16 + hi * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * a.scale_log2e);
-    }
-    // the groups steps -2 and -1 would have issued: {K(2), V(0)}, {K(3), V(1)}; K(1) before them
-    dma_k(1, 1); dma_k(2, 2); dma_v(0, 0); dma_k(3, 3); dma_v(1, 1);      // in flight after K(0) and Q: 10 pieces
-
-    f32x16 oacc[DT], negm, s[2][2];              // s[par]: S(t) of the steps with t % 2 == par, s[par ^ 1]: S(t+1)
-    half8_t p[4];                                // P fragments [kt * 2 + tt] (fp16): P(t-1) until consumed, then P(t)
-    float l_run = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-
-    // A-operand fragments: LDS byte address = off4[c] + immediate, c = 16-byte chunk pair of the row (K: depth step k; V^T: 16-key
-    // step kt * 2 + tt), immediate = ring stage * TILE + 32-row half * 4096 (K: keys kt; V^T: d half i)
-    const int fsw = (l31 >> 1) & 7;
-    unsigned off4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) off4[c] = (unsigned)(size_t)smem + l31 * 128 + ((((c << 1) | hi) ^ fsw) << 4);
-    // QK^T slot i -> keys kt = i & 1 (the two accumulator chains alternate), depth step k = i >> 1;
-    // PV slot j -> 16-key step c = j >> 1 (kt = j >> 2, tt = (j >> 1) & 1), d half i = j & 1
-    // (operands go through locals: clang rejects asm operands that name captures of an enclosing generic lambda)
-#define ATTN64W_LDS_READ(dst, c, imm) do { half8_t f_; const unsigned a_ = off4[c]; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f_) : "v"(a_), "n"(imm)); dst = f_; } while (0)
-#define ATTN64W_LDS_WAIT(n, frag) do { half8_t f_ = frag; asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(f_)); frag = f_; } while (0)
-
-    // ---- tile 0: S(0), its maximum becomes the reference ----
-    if constexpr (!(DIAG & 1)) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if constexpr (DIAG & 8) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) p[f] = qf[0];
-    }
-#pragma unroll
-    for (int i = 0; i < NQK; ++i) {
-        half8_t kf;
-        if constexpr (DIAG & 4) kf = qf[0];
-        else if (i & 1) { switch (i >> 1) { case 0: ATTN64W_LDS_READ(kf, 0, 4096); break; case 1: ATTN64W_LDS_READ(kf, 1, 4096); break; case 2: ATTN64W_LDS_READ(kf, 2, 4096); break; default: ATTN64W_LDS_READ(kf, 3, 4096); } }
-        else            { switch (i >> 1) { case 0: ATTN64W_LDS_READ(kf, 0, 0); break; case 1: ATTN64W_LDS_READ(kf, 1, 0); break; case 2: ATTN64W_LDS_READ(kf, 2, 0); break; default: ATTN64W_LDS_READ(kf, 3, 0); } }
-        ATTN64W_LDS_WAIT(0, kf);
-        s[0][i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[i >> 1], (i >> 1) == 0 ? negm : s[0][i & 1], 0, 0, 0);
-    }
-    {
-        float mx = s[0][0][0];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[0][kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[r] = -mx;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[0][kt][r] -= mx;
-    }
-
-    // one step; QK: tile t+1 exists, SM: tile t exists, PV: tile t-1 exists; PH = t % 4
-    // PH >= 0: the ring stages are immediates; PH = -1 (the last and the drain step, run once each): stages from t at run time,
-    // PAR given separately
-    auto step = [&](auto qk_c, auto sm_c, auto pv_c, auto ph_c, auto par_c, int t) {
-        constexpr bool QK = decltype(qk_c)::value, SM = decltype(sm_c)::value, PV = decltype(pv_c)::value;
-        constexpr int PH = decltype(ph_c)::value, PAR = decltype(par_c)::value;
-        static_assert(PH < 0 || (PH & 1) == PAR, "phase and parity agree");
-        constexpr int NS = (QK ? NQK : 0) + (PV ? NPV : 0), Q0 = QK ? NQK : 0;
-        constexpr int KST = PH < 0 ? 0 : ((PH + 1) & 3) * TILE;               // K(t+1)
-        constexpr int VST = PH < 0 ? 0 : (4 + ((PH + 3) & 3)) * TILE;         // V^T(t-1)
-        const unsigned vst_rt = PH < 0 ? (unsigned)((4 + ((t + 3) & 3)) * TILE) : 0u;   // (only the PV fragments are read by PH < 0 steps)
-        f32x16 (&sC)[2] = s[PAR];
-        f32x16 (&sN)[2] = s[PAR ^ 1];
-        // DMA pieces that may stay in flight: the groups steps t-2 and t-1 issued = {K(t+2), V(t)} and {K(t+3), V(t+1)}
-        // (only DMA pieces are outstanding here, and they complete in order)
-        if constexpr (!(DIAG & 1)) {
-            const int r = ntiles - t;
-            if (r >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (r == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (r == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (r == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if constexpr (!(DIAG & 2)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (PH >= 0) {                 // (the PH < 0 steps have nothing left to fetch)
-            if (t + 4 < ntiles) dma_k(t + 4, PH);
-            if (t + 2 < ntiles) dma_v(t + 2, (PH + 2) & 3);
-        }
-
-        half8_t fr[NS > 0 ? NS : 1];             // A operands, read two slots ahead of their MFMA
-        auto read = [&](auto n_c) {
-            constexpr int n = decltype(n_c)::value;
-            if constexpr (DIAG & 4) { fr[n] = qf[0]; asm volatile("" : "+v"(fr[n])); }
-            else if constexpr (n < Q0) { ATTN64W_LDS_READ(fr[n], n >> 1, KST + (n & 1) * 4096); }
-            else if constexpr (PH >= 0) { ATTN64W_LDS_READ(fr[n], (n - Q0) >> 1, VST + ((n - Q0) & 1) * 4096); }
-            else { half8_t f_; const unsigned a_ = off4[(n - Q0) >> 1] + vst_rt; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f_) : "v"(a_), "n"(((n - Q0) & 1) * 4096)); fr[n] = f_; }
-        };
-        float mxacc = 0.f;
-        f32x2 ps = {0.f, 0.f};
-        auto exps = [&](int e0, int n) {         // exponentials e0 .. e0+n-1 of S(t), in place (e = kt * 16 + r)
-            if constexpr (DIAG & 8) return;
-#pragma unroll
-            for (int e = e0; e < e0 + n; ++e) sC[e >> 4][e & 15] = __builtin_amdgcn_exp2f(sC[e >> 4][e & 15]);
-        };
-        auto pack = [&](int f) {                 // P(t) fragment f = S(t)[kt = f >> 1][8 * (f & 1) .. +7] in fp16 (+ its share of the denominator)
-            if constexpr (DIAG & 8) return;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) p[f][j] = (half_t)sC[f >> 1][8 * (f & 1) + j];
-            if constexpr (!ONES) {
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) ps += (f32x2){sC[f >> 1][8 * (f & 1) + j], sC[f >> 1][8 * (f & 1) + j + 1]};
-            }
-        };
-        auto scan = [&](int m) {                 // running-max scan #m (0..15) over S(t+1): two scores each
-            if constexpr (DIAG & 8) { if (m == 0) mxacc = sN[0][0]; return; }
-            const int kt = m >> 3, r = 2 * (m & 7);
-            mxacc = m == 0 ? fmaxf(sN[kt][r], sN[kt][r + 1]) : fmaxf(fmaxf(mxacc, sN[kt][r]), sN[kt][r + 1]);
-        };
-        auto slot = [&](auto n_c) {
-            constexpr int n = decltype(n_c)::value;
-            if constexpr (n + LA < NS) read(std::integral_constant<int, n + LA>{});
-            if constexpr (!(DIAG & 4)) {         // fragment n landed once at most the younger reads (<= LA) are outstanding
-                constexpr int YOUNGER = (NS - 1 - n) < LA ? (NS - 1 - n) : LA;
-                if constexpr (YOUNGER == 0) ATTN64W_LDS_WAIT(0, fr[n]);
-                else if constexpr (YOUNGER == 1) ATTN64W_LDS_WAIT(1, fr[n]);
-                else if constexpr (YOUNGER == 2) ATTN64W_LDS_WAIT(2, fr[n]);
-                else if constexpr (YOUNGER == 3) ATTN64W_LDS_WAIT(3, fr[n]);
-                else if constexpr (YOUNGER == 4) ATTN64W_LDS_WAIT(4, fr[n]);
-                else if constexpr (YOUNGER == 5) ATTN64W_LDS_WAIT(5, fr[n]);
-                else ATTN64W_LDS_WAIT(6, fr[n]);
-                static_assert(LA <= 6, "");
-            }
-            if constexpr (n < Q0) {
-                sN[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[n], qf[n >> 1], (n >> 1) == 0 ? negm : sN[n & 1], 0, 0, 0);
-                if constexpr (SM) exps(n * EPQ, EPQ);
-            } else {
-                constexpr int j = n - Q0;
-                oacc[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[n], p[j >> 1], oacc[j & 1], 0, 0, 0);
-                if constexpr (SM) {
-                    if constexpr (!QK && j == 0) exps(0, 24);              // (last step: no QK^T slots carried them)
-                    if constexpr (j < 4) exps(24 + 2 * j, 2);
-                    if constexpr (j == 3) pack(0);
-                    if constexpr (j == 5) pack(1);
-                    if constexpr (j == 7) pack(2);
-                }
-                if constexpr (QK) { scan(2 * j); scan(2 * j + 1); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        if constexpr (NS > 0 && LA > 0) read(std::integral_constant<int, 0>{});
-        if constexpr (NS > 1 && LA > 1) read(std::integral_constant<int, 1>{});
-        if constexpr (NS > 2 && LA > 2) read(std::integral_constant<int, 2>{});
-        if constexpr (NS > 3 && LA > 3) read(std::integral_constant<int, 3>{});
-        if constexpr (NS > 4 && LA > 4) read(std::integral_constant<int, 4>{});
-        if constexpr (NS > 5 && LA > 5) read(std::integral_constant<int, 5>{});
-#define ATTN64W_SLOT(i) if constexpr (i < NS) slot(std::integral_constant<int, i>{});
-        ATTN64W_SLOT(0) ATTN64W_SLOT(1) ATTN64W_SLOT(2) ATTN64W_SLOT(3) ATTN64W_SLOT(4) ATTN64W_SLOT(5) ATTN64W_SLOT(6) ATTN64W_SLOT(7)
-        ATTN64W_SLOT(8) ATTN64W_SLOT(9) ATTN64W_SLOT(10) ATTN64W_SLOT(11) ATTN64W_SLOT(12) ATTN64W_SLOT(13) ATTN64W_SLOT(14) ATTN64W_SLOT(15)
-#undef ATTN64W_SLOT
-        if constexpr (SM) {
-            if constexpr (!PV) { exps(24, 8); pack(0); pack(1); pack(2); }     // (first step: no PV slots carried them)
-            pack(3);
-            if constexpr (!ONES) l_run += ps[0] + ps[1];
-        }
-        if constexpr (QK) {
-            if constexpr (!PV) {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) scan(m);
-            }
-            float mx = fmaxf(mxacc, __shfl_xor(mxacc, 32));
-            if (!__all(mx <= RESCALE_THR)) {     // rare: re-reference by an integer number of octaves (exact for the packed P(t))
-                const float delta = ceilf(fmaxf(mx, 0.f));
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                const half_t alpha_h = (half_t)alpha;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) p[f][j] *= alpha_h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negm[r] -= delta;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sN[kt][r] -= delta;
-            }
-        }
-    };
-    using T_ = std::integral_constant<bool, true>;
-    using F_ = std::integral_constant<bool, false>;
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using I3 = std::integral_constant<int, 3>; using IM = std::integral_constant<int, -1>;
-    step(T_{}, T_{}, F_{}, I0{}, I0{}, 0);
-    int t = 1;                                   // (t % 4 == 1 at the top of every round of four and after the loop)
-    for (; t + 4 < ntiles; t += 4) {
-        step(T_{}, T_{}, T_{}, I1{}, I1{}, t);
-        step(T_{}, T_{}, T_{}, I2{}, I0{}, t + 1);
-        step(T_{}, T_{}, T_{}, I3{}, I1{}, t + 2);
-        step(T_{}, T_{}, T_{}, I0{}, I0{}, t + 3);
-    }
-    if (t + 1 < ntiles) { step(T_{}, T_{}, T_{}, I1{}, I1{}, t); ++t; }
-    if (t + 1 < ntiles) { step(T_{}, T_{}, T_{}, I2{}, I0{}, t); ++t; }
-    if (t + 1 < ntiles) { step(T_{}, T_{}, T_{}, I3{}, I1{}, t); ++t; }
-    // t == ntiles - 1: last softmax, no tile t+1; then the drain step accumulates P(ntiles-1)
-    if (t & 1) step(F_{}, T_{}, T_{}, IM{}, I1{}, t); else step(F_{}, T_{}, T_{}, IM{}, I0{}, t);
-    step(F_{}, F_{}, T_{}, IM{}, I0{}, t + 1);
-#undef ATTN64W_LDS_READ
-#undef ATTN64W_LDS_WAIT
-
-    // ---- finalize: O = O^T / l, store token-major (as attn64_kernel) ----
-    int lane_f = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane_f));
-    const int l31_f = lane_f & 31, hi_f = lane_f >> 5;
-    float l_tot;
-    if constexpr (ONES) {
-        const int dr = a.d & 31;
-        float lv = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) if (dr == 8 * g) lv = oacc[DT - 1][4 * g];
-        l_tot = __shfl(lv, l31_f);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32);
-    }
-    const float inv_l = 1.0f / l_tot;
-    const int q = qb * 128 + wid * 32 + l31_f;
-    if (q < a.nq) {
-        const int b = bh / a.heads, head = bh - b * a.heads;
-        half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = i * 32 + 8 * g + 4 * hi_f;
-                if (dd < a.d) {
-                    half4_t o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = (half_t)(oacc[i][4 * g + k] * inv_l);
-                    *reinterpret_cast<half4_t*>(orow + dd) = o;
-                }
-            }
-    }
-}
-
 // ---- cross-attention, dp = 64, <= 128 keys (the 77 text tokens) ----------------------------------------------------------
 // With 77 keys the flash loop above is two tiles of latency per 128 queries: every workgroup loads its own copy of K / V^T
 // (32 KB) for 16 KB of Q and 16 KB of O, waits for it twice and runs the online-softmax bookkeeping for nothing
@@ -991,19 +663,6 @@ int launch_attn64(const AttnArgs& a, dim3 grid, hipStream_t s) {
     return 0;
 }
 
-template <int D16, bool ONES, int DIAG = 0, int LA = 2>
-int launch_attn64w(const AttnArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem = 8 * 64 * 128;
-    static bool attr_set = false;
-    auto kern = attn64w_kernel<D16, ONES, DIAG, LA>;
-    if (!attr_set) {
-        CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
-    return 0;
-}
-
 // sets row d of every V^T matrix to 1.0 (see the kernel header); vt [BH][dp][tok_pad]
 __global__ void attn_ones_row_kernel(half_t* vt, int BH, int d, int dp, int tok_pad) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1028,15 +687,17 @@ int launch_attn(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-static int g_attn_dma = 1;       // dp = 64: 2 = + the woven kernel for >= 2048 keys (3: >= 256), 1 = LDS-DMA flash loop, 0 = register-staged kernel (A/B switch).  (A software-pipelined form
+static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel, 0 = register-staged kernel (A/B switch).  (A software-pipelined form
                                  // with two score tiles live was built and measured in round 3 - correct, 8 % slower: fewer resident waves -
-                                 // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt)
+                                 // and removed in round 4; profiles/r03/ab/attention_variants_alone.txt.  Round 4's woven form - QK^T of
+                                 // tile t+1 and PV of tile t-1 issued between slices of tile t's softmax, two workgroups per CU - was +6..11 %
+                                 // alone, neutral per forward and no better in matrix-pipe utilisation: commit 926a7ad)
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
 
-void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode < 0 ? 0 : mode > 3 ? 3 : mode; }
+void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
 
@@ -1094,28 +755,6 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     }
     if (dt == 2 && g_attn_dma) {                   // dp = 64 (d = 40, 48, 56, 64): LDS-DMA kernel
         int rc;        // (a 2-stage ring was measured within 1 % of the 3-stage one and is not built)
-        if (g_attn_dma >= 2 && nk % 64 == 0 && nk >= (g_attn_dma == 3 ? 256 : 2048)) {
-            if (d16 == 4 && !ones && g_attn_stagger) {       // timing experiments (wrong results): see DIAG
-                switch (g_attn_stagger) {
-                    case 1: rc = launch_attn64w<4, false, 1>(a, grid, s); break;
-                    case 2: rc = launch_attn64w<4, false, 2>(a, grid, s); break;
-                    case 3: rc = launch_attn64w<4, false, 3>(a, grid, s); break;
-                    case 4: rc = launch_attn64w<4, false, 4>(a, grid, s); break;
-                    case 7: rc = launch_attn64w<4, false, 7>(a, grid, s); break;
-                    case 8: rc = launch_attn64w<4, false, 8>(a, grid, s); break;
-                    case 15: rc = launch_attn64w<4, false, 15>(a, grid, s); break;
-                    case 103: rc = launch_attn64w<4, false, 0, 3>(a, grid, s); break;
-                    case 104: rc = launch_attn64w<4, false, 0, 4>(a, grid, s); break;
-                    case 106: rc = launch_attn64w<4, false, 0, 6>(a, grid, s); break;
-                    default: rc = launch_attn64w<4, false>(a, grid, s);
-                }
-            } else
-            if (d16 == 3) rc = launch_attn64w<3, true>(a, grid, s);
-            else rc = ones ? launch_attn64w<4, true>(a, grid, s) : launch_attn64w<4, false>(a, grid, s);
-            if (rc) return -1;
-            CFGPP_HIP_CHECK(hipGetLastError());
-            return 0;
-        }
         // four workgroups per CU: two-stage ring (32 KB), <= 128 VGPRs (the three-per-CU form on a 3-stage ring of rounds 2-3 measured
         // 3 - 9 % slower alone and 0.3 - 1 % per forward, profiles/r04/ab/attention_occupancy_call9.txt / _call10.txt)
         if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
