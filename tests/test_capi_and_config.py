@@ -37,6 +37,33 @@ def test_library_exports_every_declared_symbol():
     assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
 
 
+def test_shipped_kernels_have_no_spills_and_stay_in_their_register_budgets():
+    """the gfx950 code objects inside the built library: no kernel spills VGPRs or uses scratch, and the kernels whose occupancy
+    DESIGN.md counts on stay inside the register budget that occupancy needs (read from the ELF notes, scripts/kernel_resources.py)"""
+    import subprocess
+    import sys
+    from cfgpp_amd.build import build
+    build(verbose=False)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import kernel_resources as KR
+    if not os.path.exists(KR.READELF):
+        pytest.skip("llvm-readelf not found")
+    ks = KR.kernels(os.path.join(ROOT, "cfgpp_amd", "libcfgpp_hip.so"))
+    assert len(ks) > 100, f"only {len(ks)} kernels found in the code objects"
+    bad = [k["name"] for k in ks if k["spill"] != "0" or k["scratch"] != "0"]
+    assert bad == [], f"kernels with VGPR spills or scratch: {bad}"
+    names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in ks), capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for k, name in zip(ks, names):
+        v = int(k["vgpr"]) + int(k["agpr"])
+        if "::attn64_kernel<" in name:         # four workgroups per CU = four waves per SIMD
+            assert v <= 128, (name, v); seen += 1
+        if "::tile32_kernel<4, 2, 64, 64, 3, 4" in name:      # 256 x 128 tile, two 8-wave workgroups per CU = four waves per SIMD
+            assert v <= 128, (name, v); seen += 1
+        assert v <= 512, (name, v)
+    assert seen >= 4, "the occupancy-critical kernels were not found by name"
+
+
 def test_param_totals_match_published_sizes():
     from cfgpp_amd.unet_config import SD15, SDXL, param_count
     assert param_count(SD15) == 859_520_964       # 859.5 M
