@@ -167,6 +167,100 @@ __global__ void __launch_bounds__((8 + NLOAD) * 64) gemm_tile(const half_t* __re
             }
 }
 
+// ---- 256 x 256 tile, FOUR waves of 128 x 128 (one per SIMD, 256 accumulator registers each): 0.5 fragment reads and 0.25 DMA
+// pieces per MFMA instead of 1 and 0.375; 64-deep K-tiles on a 2-stage ring (2 x 64 KB); every wave issues 16 pieces per K-tile,
+// one after every fourth MFMA.  Same layouts, same check.
+constexpr int BIG = 256, BSTAGE = 2 * BIG * 128;
+template <int SKIP>
+__global__ void __launch_bounds__(256) gemm_tile_big(const half_t* __restrict__ A, float* __restrict__ C, unsigned long long* cyc, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkt = K / BK;
+    const int r8 = lane >> 3, pc = lane & 7;
+    unsigned src[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (wid + i * 4) * 8 + r8;
+        src[i] = (unsigned)(row * K + ((pc ^ ((row >> 1) & 7)) * 8));
+    }
+    auto issue_piece = [&](int kt, int i) {
+        if (SKIP) return;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)kt * BK + src[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + (kt & 1) * BSTAGE + (wid + i * 4) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) issue_piece(0, i);
+    const int l31 = lane & 31, hi = lane >> 5, fsw = (l31 >> 1) & 7;
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = (wm * 128 + l31) * 128, brow = (BIG + wn * 128 + l31) * 128;
+    auto frag = [&](const char* st, int rowoff, int q32, int ks) {
+        return *reinterpret_cast<const half8_t*>(st + rowoff + q32 * 32 * 128 + ((((ks << 1) | hi) ^ fsw) << 4));
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + (kt & 1) * BSTAGE;
+        const bool more = kt + 1 < nkt;
+        half8_t af[2][4], bf[2][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { af[0][h] = frag(st, arow, h, 0); bf[0][h] = frag(st, brow, h, 0); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { af[(ks + 1) & 1][h] = frag(st, arow, h, ks + 1); bf[(ks + 1) & 1][h] = frag(st, brow, h, ks + 1); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    const int m = ks * 16 + i * 4 + j;
+                    if ((m & 3) == 3 && more) issue_piece(kt + 1, m >> 2);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && wid == 0) cyc[blockIdx.x] = t1 - t0;
+    float* Cb = C + (long)(blockIdx.x & 1) * BIG * BIG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = wn * 128 + j * 32 + l31;
+                Cb[row * BIG + col] = acc[i][j][r];
+            }
+}
+
+template <int SKIP>
+double run_big(const half_t* dA, float* dC, unsigned long long* dcyc, int K, int grid, int reps, double* cyc_per_kt) {
+    auto kern = gemm_tile_big<SKIP>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BSTAGE);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * BSTAGE, 0, dA, dC, dcyc, K);
+    (void)hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * BSTAGE, 0, dA, dC, dcyc, K);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(grid);
+    (void)hipMemcpy(h.data(), dcyc, grid * 8, hipMemcpyDeviceToHost);
+    double s = 0; for (auto v : h) s += (double)v;
+    *cyc_per_kt = s / grid / (K / BK);
+    return ms / reps * 1e3;
+}
+
 template <int NLOAD, int PRIO, int SKIP = 0, int SKEW = 0>
 double run(const half_t* dA, float* dC, unsigned long long* dcyc, int K, int grid, int reps, double* cyc_per_kt) {
     auto kern = gemm_tile<NLOAD, PRIO, SKIP, SKEW>;
@@ -186,11 +280,11 @@ double run(const half_t* dA, float* dC, unsigned long long* dcyc, int K, int gri
 
 int main() {
     const int KMAX = 4096;
-    std::vector<half_t> hA((size_t)(BM + BN) * KMAX);
+    std::vector<half_t> hA((size_t)512 * KMAX);            // 512 rows: enough for the 256 x 256 kernel's A-then-B image too
     srand(1);
     for (auto& v : hA) v = (half_t)(((rand() % 2001) - 1000) / 4000.0f);
     half_t* dA; float* dC; unsigned long long* dcyc;
-    (void)hipMalloc(&dA, hA.size() * 2); (void)hipMalloc(&dC, 2 * BM * BN * 4); (void)hipMalloc(&dcyc, 4096 * 8);
+    (void)hipMalloc(&dA, hA.size() * 2); (void)hipMalloc(&dC, 2 * 256 * 256 * 4); (void)hipMalloc(&dcyc, 4096 * 8);
     std::vector<float> hC(BM * BN);
     // ---- correctness at K = 256 (rows of the image are K apart: re-pack for this K) ----
     {
@@ -211,6 +305,17 @@ int main() {
         (void)hipMemset(dC, 0, 2 * BM * BN * 4); run<4, 0>(dA, dC, dcyc, K, 2, 1, &cpk); check("4 loader waves");
         (void)hipMemset(dC, 0, 2 * BM * BN * 4); run<4, 1>(dA, dC, dcyc, K, 2, 1, &cpk); check("4 loader waves, prio");
     }
+    {
+        const int K = 256;
+        std::vector<half_t> a((size_t)512 * K);
+        for (int r = 0; r < 512; ++r) for (int k = 0; k < K; ++k) a[(size_t)r * K + k] = hA[(size_t)r * KMAX + k];
+        (void)hipMemcpy(dA, a.data(), a.size() * 2, hipMemcpyHostToDevice);
+        double cpk; (void)hipMemset(dC, 0, 2 * 256 * 256 * 4); run_big<0>(dA, dC, dcyc, K, 2, 1, &cpk);
+        std::vector<float> c(256 * 256); (void)hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+        double e = 0, rr = 0;
+        for (int m = 0; m < 256; ++m) for (int n = 0; n < 256; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)(float)a[(size_t)m * K + k] * (double)(float)a[(size_t)(256 + n) * K + k]; e += (c[m * 256 + n] - s) * (c[m * 256 + n] - s); rr += s * s; }
+        printf("check %-22s K=256: rel-L2 vs fp64 host reference %.2e\n", "256x256, 4 waves", std::sqrt(e / rr));
+    }
     (void)hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
     printf("%-26s %6s %10s %10s %16s %12s\n", "variant", "WGs", "us", "TFLOP/s", "cycles / K-tile", "MFMA util");
     for (int grid : {1, 256, 1024}) {
@@ -223,6 +328,9 @@ int main() {
         us = run<4, 0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
         us = run<4, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves, prio 3", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
         us = run<0, 0, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "all waves load, A only", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        { const double fb = 2.0 * 256 * 256 * K * grid;      // 256 x 256 tile: 64 MFMAs = 2048 matrix cycles per K-tile and SIMD (one wave)
+          us = run_big<0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, 4 waves of 128x128", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
+          us = run_big<1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, nothing loaded", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk); }
         us = run<0, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "nothing loaded", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
         us = run<4, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 idle loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
     }
