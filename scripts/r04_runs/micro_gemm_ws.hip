@@ -1,4 +1,4 @@
-// Does a loader-wave / MFMA-wave split lift the K loop of an LDS-DMA GEMM tile?  (a 1 KB LDS-DMA piece costs the
+// Stand-alone K loops of an LDS-DMA GEMM tile: does a loader-wave / MFMA-wave split lift it?  An early barrier?  Bigger wave tiles?  (a 1 KB LDS-DMA piece costs the
 // issuing wave 60-185 cycles, and in the shipped kernels the waves that own accumulators issue them.)
 // One 256 x 128 fp16 tile per workgroup, 64-deep K-tiles, 3-stage LDS ring (48 KB per stage: A rows [256][128 B] then B rows
 // [128][128 B], XOR-swizzled 16-byte chunks, 8-row DMA pieces - the layouts of cfgpp_amd/csrc), 8 MFMA waves of 64 x 64 each
