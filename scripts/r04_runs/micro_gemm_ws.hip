@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 typedef _Float16 half_t;
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__((8 + NLOAD) * 64) gemm_tile(const half_t* __re
 // pieces per MFMA instead of 1 and 0.375; 64-deep K-tiles on a 2-stage ring (2 x 64 KB); every wave issues 16 pieces per K-tile,
 // one after every fourth MFMA.  Same layouts, same check.
 constexpr int BIG = 256, BSTAGE = 2 * BIG * 128;
-template <int SKIP>
+template <bool SKIP>
 __global__ void __launch_bounds__(256) gemm_tile_big(const half_t* __restrict__ A, float* __restrict__ C, unsigned long long* cyc, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -244,9 +245,181 @@ __global__ void __launch_bounds__(256) gemm_tile_big(const half_t* __restrict__ 
             }
 }
 
+// ---- the same 256 x 256 four-wave loop with the piece issue slimmed down: the last K-tile is peeled (no branch around a piece), a
+// piece is `s_mov m0 ; global_load_lds_dwordx4 v_off32, s[base]` (scalar tile base + 32-bit per-lane byte offset: no 64-bit vector
+// add per piece, and the offset registers are the piece's own), and the 16 pieces go out after every third of the first 48 MFMAs.
+template <int DUMMY>
+__global__ void __launch_bounds__(256) gemm_tile_big2(const half_t* __restrict__ A, float* __restrict__ C, unsigned long long* cyc, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkt = K / BK;
+    const int r8 = lane >> 3, pc = lane & 7;
+    unsigned src[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (wid + i * 4) * 8 + r8;
+        src[i] = (unsigned)(row * K + ((pc ^ ((row >> 1) & 7)) * 8)) * 2u;       // bytes
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem + wid * 1024;
+    auto issue_piece = [&](int kt, int i) {
+        const char* base = reinterpret_cast<const char*>(A) + (long)kt * BK * 2;            // wave-uniform
+        const unsigned m0v = lds0 + (kt & 1) * BSTAGE + i * 4096;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(src[i]), "s"(base) : "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) issue_piece(0, i);
+    const int l31 = lane & 31, hi = lane >> 5, fsw = (l31 >> 1) & 7;
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = (wm * 128 + l31) * 128, brow = (BIG + wn * 128 + l31) * 128;
+    auto frag = [&](const char* st, int rowoff, int q32, int ks) {
+        return *reinterpret_cast<const half8_t*>(st + rowoff + q32 * 32 * 128 + ((((ks << 1) | hi) ^ fsw) << 4));
+    };
+    auto tile = [&](auto more_c, int kt) {
+        constexpr bool MORE = decltype(more_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* st = smem + (kt & 1) * BSTAGE;
+        half8_t af[2][4], bf[2][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { af[0][h] = frag(st, arow, h, 0); bf[0][h] = frag(st, brow, h, 0); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { af[(ks + 1) & 1][h] = frag(st, arow, h, ks + 1); bf[(ks + 1) & 1][h] = frag(st, brow, h, ks + 1); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    const int m = ks * 16 + i * 4 + j;
+                    if constexpr (MORE) { if (m < 48 && m % 3 == 2) issue_piece(kt + 1, m / 3); }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt + 1 < nkt; ++kt) tile(std::integral_constant<bool, true>{}, kt);
+    tile(std::integral_constant<bool, false>{}, nkt - 1);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && wid == 0) cyc[blockIdx.x] = t1 - t0;
+    float* Cb = C + (long)(blockIdx.x & 1) * BIG * BIG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = wn * 128 + j * 32 + l31;
+                Cb[row * BIG + col] = acc[i][j][r];
+            }
+}
+
+// ---- ... and with the barrier that publishes tile kt+1 moved BEFORE the last 16-deep step of tile kt (its fragments are already in
+// registers): right after it the first fragments of tile kt+1 are read, and that step's 16 MFMAs cover their latency; the 16 pieces
+// of tile kt+2 go out under those MFMAs (8) and under the first step of tile kt+1 (8), i.e. as soon as tile kt's stage is free.
+template <bool LOAD>
+__global__ void __launch_bounds__(256) gemm_tile_big3(const half_t* __restrict__ A, float* __restrict__ C, unsigned long long* cyc, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nkt = K / BK;                      // >= 3
+    const int r8 = lane >> 3, pc = lane & 7;
+    unsigned src[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (wid + i * 4) * 8 + r8;
+        src[i] = (unsigned)(row * K + ((pc ^ ((row >> 1) & 7)) * 8)) * 2u;
+    }
+    const unsigned lds0 = (unsigned)(size_t)smem + wid * 1024;
+    auto issue_piece = [&](int kt, int i) {
+        if constexpr (!LOAD) return;
+        const char* base = reinterpret_cast<const char*>(A) + (long)kt * BK * 2;
+        const unsigned m0v = lds0 + (kt & 1) * BSTAGE + i * 4096;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(src[i]), "s"(base) : "memory");
+    };
+    const int l31 = lane & 31, hi = lane >> 5, fsw = (l31 >> 1) & 7;
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = (wm * 128 + l31) * 128, brow = (BIG + wn * 128 + l31) * 128;
+    auto frag = [&](const char* st, int rowoff, int q32, int ks) {
+        return *reinterpret_cast<const half8_t*>(st + rowoff + q32 * 32 * 128 + ((((ks << 1) | hi) ^ fsw) << 4));
+    };
+    half8_t af[2][4], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) issue_piece(0, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { af[0][h] = frag(smem, arow, h, 0); bf[0][h] = frag(smem, brow, h, 0); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_piece(1, i);
+    // P0: pieces 8..15 of tile kt+1 under step 0; BAR: tile kt+1 exists (barrier + its first fragments before step 3); P3: pieces 0..7 of tile kt+2 under step 3
+    auto tile = [&](auto p0_c, auto bar_c, auto p3_c, int kt) {
+        constexpr bool P0 = decltype(p0_c)::value, BAR = decltype(bar_c)::value, P3 = decltype(p3_c)::value;
+        const char* st = smem + (kt & 1) * BSTAGE;
+        const char* stn = smem + ((kt + 1) & 1) * BSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { af[(ks + 1) & 1][h] = frag(st, arow, h, ks + 1); bf[(ks + 1) & 1][h] = frag(st, brow, h, ks + 1); }
+            } else if constexpr (BAR) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // tile kt+1 landed; every read of tile kt landed too
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int h = 0; h < 4; ++h) { af[0][h] = frag(stn, arow, h, 0); bf[0][h] = frag(stn, brow, h, 0); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    const int m = i * 4 + j;
+                    if constexpr (P0) { if (ks == 0 && (m & 1)) issue_piece(kt + 1, 8 + (m >> 1)); }
+                    if constexpr (P3) { if (ks == 3 && (m & 1)) issue_piece(kt + 2, m >> 1); }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using T_ = std::integral_constant<bool, true>; using F_ = std::integral_constant<bool, false>;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt + 2 < nkt; ++kt) tile(T_{}, T_{}, T_{}, kt);
+    tile(T_{}, T_{}, F_{}, nkt - 2);
+    tile(F_{}, F_{}, F_{}, nkt - 1);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && wid == 0) cyc[blockIdx.x] = t1 - t0;
+    float* Cb = C + (long)(blockIdx.x & 1) * BIG * BIG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, col = wn * 128 + j * 32 + l31;
+                Cb[row * BIG + col] = acc[i][j][r];
+            }
+}
+
 template <int SKIP>
 double run_big(const half_t* dA, float* dC, unsigned long long* dcyc, int K, int grid, int reps, double* cyc_per_kt) {
-    auto kern = gemm_tile_big<SKIP>;
+    auto kern = SKIP == 4 ? gemm_tile_big3<false> : SKIP == 3 ? gemm_tile_big3<true> : SKIP == 2 ? gemm_tile_big2<0> : gemm_tile_big<(SKIP == 1)>;   // 2 = slim issue, 3 = + early barrier, 4 = early barrier, nothing loaded
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BSTAGE);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 2 * BSTAGE, 0, dA, dC, dcyc, K);
@@ -315,24 +488,37 @@ int main() {
         double e = 0, rr = 0;
         for (int m = 0; m < 256; ++m) for (int n = 0; n < 256; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)(float)a[(size_t)m * K + k] * (double)(float)a[(size_t)(256 + n) * K + k]; e += (c[m * 256 + n] - s) * (c[m * 256 + n] - s); rr += s * s; }
         printf("check %-22s K=256: rel-L2 vs fp64 host reference %.2e\n", "256x256, 4 waves", std::sqrt(e / rr));
+        (void)hipMemset(dC, 0, 2 * 256 * 256 * 4); run_big<2>(dA, dC, dcyc, K, 2, 1, &cpk);
+        (void)hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+        e = 0; rr = 0;
+        for (int m = 0; m < 256; ++m) for (int n = 0; n < 256; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)(float)a[(size_t)m * K + k] * (double)(float)a[(size_t)(256 + n) * K + k]; e += (c[m * 256 + n] - s) * (c[m * 256 + n] - s); rr += s * s; }
+        printf("check %-22s K=256: rel-L2 vs fp64 host reference %.2e\n", "256x256, slim issue", std::sqrt(e / rr));
+        (void)hipMemset(dC, 0, 2 * 256 * 256 * 4); run_big<3>(dA, dC, dcyc, K, 2, 1, &cpk);
+        (void)hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+        e = 0; rr = 0;
+        for (int m = 0; m < 256; ++m) for (int n = 0; n < 256; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)(float)a[(size_t)m * K + k] * (double)(float)a[(size_t)(256 + n) * K + k]; e += (c[m * 256 + n] - s) * (c[m * 256 + n] - s); rr += s * s; }
+        printf("check %-22s K=256: rel-L2 vs fp64 host reference %.2e\n", "256x256, early barrier", std::sqrt(e / rr));
     }
     (void)hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
-    printf("%-26s %6s %10s %10s %16s %12s\n", "variant", "WGs", "us", "TFLOP/s", "cycles / K-tile", "MFMA util");
+    printf("%-30s %6s %10s %10s %16s %12s\n", "variant", "WGs", "us", "TFLOP/s", "cycles / K-tile", "MFMA util");
     for (int grid : {1, 256, 1024}) {
         const int K = KMAX, reps = grid == 1 ? 5 : 20;
         const double flops = 2.0 * BM * BN * K * grid;
         double cpk, us;
-        us = run<0, 0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "all waves load", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<0, 0, 0, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "skewed barrier", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<0, 0, 2, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "skewed, nothing loaded", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<4, 0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<4, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves, prio 3", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<0, 0, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "all waves load, A only", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<0, 0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "all waves load", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<0, 0, 0, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "skewed barrier", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<0, 0, 2, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "skewed, nothing loaded", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<4, 0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<4, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 loader waves, prio 3", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<0, 0, 1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "all waves load, A only", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
         { const double fb = 2.0 * 256 * 256 * K * grid;      // 256 x 256 tile: 64 MFMAs = 2048 matrix cycles per K-tile and SIMD (one wave)
-          us = run_big<0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, 4 waves of 128x128", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
-          us = run_big<1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, nothing loaded", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk); }
-        us = run<0, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "nothing loaded", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
-        us = run<4, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-26s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 idle loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+          us = run_big<0>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, 4 waves of 128x128", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
+          us = run_big<2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, slim piece issue", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
+          us = run_big<3>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, slim + early barrier", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
+          us = run_big<4>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, early bar., no loads", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk);
+          us = run_big<1>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "256x256, nothing loaded", grid, us, fb / us / 1e6, cpk, 2048.0 / cpk); }
+        us = run<0, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "nothing loaded", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
+        us = run<4, 0, 2>(dA, dC, dcyc, K, grid, reps, &cpk); printf("%-30s %6d %10.1f %10.1f %16.1f %12.3f\n", "4 idle loader waves", grid, us, flops / us / 1e6, cpk, 1024.0 / cpk);
     }
     printf("# MFMA util = 1024 matrix cycles per K-tile and SIMD (2 waves x 16 x 32) / measured shader cycles per K-tile (wave 0 of each workgroup)\n");
     return 0;
