@@ -10,8 +10,10 @@ exactly what ``solver.sample()`` returns in the reference
 (latent_diffusion.py:634-679).  Default workload = BASELINE.json configs[1]:
 SD1.5 512x512, ddim_cfg++, 50 NFE, lambda = 0.6, batch 8 on one MI355X.  With
 N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the
-same per-GPU batch (weak scaling) on its own prompt shard; rank 0 broadcasts the
-conditioning once over RCCL; nothing is exchanged inside the loop.
+same per-GPU batch (weak scaling; ``--global-batch G`` fixes the TOTAL batch and gives
+every rank G / N chains instead: strong scaling, BASELINE configs 3 - 5 as written) on its
+own prompt shard; rank 0 broadcasts the conditioning once over RCCL; nothing is exchanged
+inside the loop.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the fields).
 """
@@ -60,7 +62,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="sd15", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (weak scaling: fixed work per GPU)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: total batch of the job, split evenly over the --gpus ranks (BASELINE configs 3/4/5 are "
+                         "global batches: --config sdxl --global-batch 16, sdxl_lightning 64, sdxl_edit 8 at 1/2/4/8 GPUs)")
     ap.add_argument("--nfe", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -316,7 +321,7 @@ def prepare_job(solver, cfg, kind, name, B, img, lam, rank, world, dev):
     return one_job, total
 
 
-def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_override=0, with_cpu_baseline=True):
+def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_override=0, with_cpu_baseline=True, scaling="weak"):
     """build the engine of one WORKLOADS entry, share rank 0's tile pins, warm up, time `steps` jobs between barriers
     (max over ranks) and return the JSON fields of that workload"""
     from cfgpp_amd import dist as D
@@ -371,7 +376,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     flat = [x for r in per_rank for x in r]
     result = {
         "metric": "images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
         "config": {"workload": desc, "per_gpu_batch": B, "global_batch": total, "nfe": nfe, "lambda": lam,
                    "unet_batch_rows": rows, "includes": ("VAE encode (HIP kernels), " if "inversion" in name else "") +
@@ -380,7 +385,8 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
                    "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
         "ranks": {"job_ms_min": round(min(flat) * 1e3, 2), "job_ms_max": round(max(flat) * 1e3, 2),
                   "job_ms_mean_per_rank": [round(sum(r) / len(r) * 1e3, 2) for r in per_rank],
-                  "conditioning_broadcast_ms": round(broadcast_ms, 3), "tile_tuning": tuning},
+                  "conditioning_broadcast_ms": round(broadcast_ms, 3), "tile_tuning": tuning,
+                  "identity": [json.loads(x) for x in D.gather_strings(D.rank_identity(dev), dev)]},
     }
     if rank == 0 and not args.no_profile:
         result["roofline"] = roofline_block(eng, config, B, dev, PROFILE_ROUND)
@@ -440,8 +446,16 @@ def main():
         # never a silent 1-GPU run under an N-GPU label (or the reverse)
         raise SystemExit(f"--gpus {args.gpus} but the job has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')})")
     dev = device_for(local_rank)
-    result = run_workload(args, args.config, rank, world, dev, args.steps, args.warmup, args.batch, args.nfe)
-    if args.config == "sd15" and not args.no_also and not args.batch and not args.nfe:
+    batch, scaling = args.batch, "weak"
+    if args.global_batch:
+        # strong scaling: the job's total batch is fixed, every rank takes an equal share (BASELINE configs 3 - 5 as written)
+        if args.batch:
+            raise SystemExit("--batch (per-GPU, weak scaling) and --global-batch (total, strong scaling) exclude each other")
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} rank(s)")
+        batch, scaling = args.global_batch // world, "strong"
+    result = run_workload(args, args.config, rank, world, dev, args.steps, args.warmup, batch, args.nfe, scaling=scaling)
+    if args.config == "sd15" and not args.no_also and not batch and not args.nfe:
         # BASELINE.json's metric names SD1.5 512^2 AND SDXL 1024^2: the default command also times a short SDXL leg
         # (configs[2]'s per-GPU share: batch 2 per GPU, 50 NFE) - 1 warm-up job (in-situ tuning) + 2 timed jobs
         import gc

@@ -20,6 +20,7 @@ SOURCES = [
     ("norm_kernels.hip", []),
     ("small_kernels.hip", []),
     ("igemm_kernel.hip", []),
+    ("big4_kernel.hip", []),
     ("attn_kernel.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # scores are consumed by VALU: keep MFMA results in VGPRs
     ("unet.hip", []),
     ("vae.hip", []),
@@ -35,13 +36,36 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+_INC = None
+
+
+def _deps(src: str) -> set:
+    """the quoted headers `src` includes, transitively (csrc/ and include/ only): a TU is rebuilt when one of ITS headers changed,
+    not when any header did (igemm_kernel.hip alone takes minutes)"""
+    import re
+    global _INC
+    if _INC is None:
+        _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f, errors="replace").read()
+        except OSError:
+            continue
+        for inc in _INC.findall(text):
+            h = os.path.normpath(os.path.join(os.path.dirname(f), inc))
+            if h not in seen and os.path.exists(h):
+                seen.add(h)
+                todo.append(h)
+    return seen
+
+
 def _newer(src: str, dst: str) -> bool:
     if not os.path.exists(dst):
         return True
     t = os.path.getmtime(dst)
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "cfgpp.h"))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in [src, *_deps(src)] if os.path.exists(d))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

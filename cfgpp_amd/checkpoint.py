@@ -38,11 +38,18 @@ def _weights_in(folder, stem="diffusion_pytorch_model"):
     return _first(os.path.join(folder, stem + ".safetensors"), os.path.join(folder, stem + ".fp16.safetensors"))
 
 
-def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None) -> Tuple[Dict, List[str]]:
+def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None, text_tower: str = "") -> Tuple[Dict, List[str]]:
     """(kwargs for ``get_solver``, names of the components not found).  ``vae_dir``: a folder holding the VAE weights,
     overriding the default lookup (SD1.5: ``<dir>/vae``; SDXL: ``<dir>/vae_fp16_fix`` or ``<dir>/sdxl-vae-fp16-fix`` -
-    NEVER ``<dir>/vae``, whose fp16 activations overflow)."""
+    NEVER ``<dir>/vae``, whose fp16 activations overflow).  ``text_tower`` (or ``$CFGPP_TEXT_TOWER``): ``"hip"`` = the HIP CLIP
+    tower or an error, ``"torch"`` = the torch-ops ``ClipTextTower`` even on a GPU; default = the HIP tower on a GPU, and when
+    that one cannot take the checkpoint (an activation it has no kernel for, keys of a fine-tune it does not know) the torch-ops
+    tower with a logged warning - the text encoder runs once per prompt and is not on the hot path."""
+    import logging
     from .conditioning import ClipTextTower
+    text_tower = (text_tower or os.environ.get("CFGPP_TEXT_TOWER", "")).lower()
+    if text_tower not in ("", "hip", "torch"):
+        raise ValueError(f"text_tower={text_tower!r}: expected 'hip', 'torch' or ''")
     d = str(model_dir)
     kw, missing = {}, []
     unet = _weights_in(os.path.join(d, "unet"))
@@ -70,9 +77,15 @@ def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None) -
         if not ok:
             missing.append(enc)
             return None
-        if on_gpu:
+        if on_gpu and text_tower != "torch":
             from .text import HipClipTextTower
-            return HipClipTextTower.from_dir(e, t, device=device, **args)
+            try:
+                return HipClipTextTower.from_dir(e, t, device=device, **args)
+            except Exception as exc:  # noqa: BLE001
+                if text_tower == "hip":
+                    raise
+                logging.getLogger("cfgpp_amd").warning("HIP text tower cannot load %s (%s: %s); using the torch-ops ClipTextTower",
+                                                       e, type(exc).__name__, exc)
         return ClipTextTower.from_dir(e, t, device=device, dtype=dtype, **args)
 
     if sdxl:

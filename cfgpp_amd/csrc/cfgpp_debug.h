@@ -89,9 +89,10 @@ void cfgpp_igemm_set_tail_split(int on);  /* 1 = K-split tiny grids with long K 
 void cfgpp_igemm_set_mf16(int mode);
 /* 1 (default): the rule also takes token-major linears; 0: convolutions only - the in-situ tuner then picks the linears' tile (A/B) */
 void cfgpp_igemm_set_mf16_linear(int on);
-/* 1: QKV / Q / KV projections (head-major epilogue) may use that tile too; default 0 until validated on hardware */
+/* 1 (default since round 3, validated on hardware): QKV / Q / KV projections (head-major epilogue) may use that tile too; 0: off */
 void cfgpp_igemm_set_mf16_heads(int on);
-/* A/B knob of that rule: also take grids of exactly 2 .. n full rounds of 256 tiles (default 1 = one round only) */
+/* A/B knob of that rule: also take grids of exactly 2 .. n full rounds of 256 tiles (default 2: the M = 16384 x N = 640 class;
+ * 1 = one round of 200 .. 256 tiles only) */
 void cfgpp_igemm_set_mf16_rounds(int n);
 /* tile of the rule-based K-split launches: 14 (default) = 256x128 on 3 stages, 1 = 128x128 on 2 stages, 12 = 128x128 on 3 stages */
 void cfgpp_igemm_set_split_tile(int cfg);
@@ -103,7 +104,8 @@ void cfgpp_igemm_set_big_split(int min_kt);
 /* tile walk of the implicit GEMM: -1 (default) by operand bytes / the tuner's pin, 0 always M-major, 1 always N-major; the
  * result does not depend on it */
 void cfgpp_igemm_set_n_major(int mode);
-/* in-situ tuning candidates: bit c set = tile config c may be pinned, bit 31 = the tile-walk stage runs (default: all) */
+/* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 26; 24 - 26 = the one-wave-per-SIMD tiles of
+ * big4_kernel.hip), bit 31 = the tile-walk stage runs (default: all) */
 void cfgpp_igemm_set_tune_mask(unsigned mask);
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins

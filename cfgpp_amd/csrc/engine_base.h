@@ -75,7 +75,7 @@ struct EngineBase {
             tuned_rows = rows;
             return 0;
         }
-        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20};
+        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24, 25, 26};
         const size_t n = plan.size();
         plan_hint.resize(n, nullptr);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -83,6 +83,7 @@ struct EngineBase {
         std::vector<hipEvent_t> ev(n + 1, nullptr);
         for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1;
         std::vector<float> base(n, 1e30f), best(n, 1e30f), t(n);
+        std::vector<char> applied(n, 1);        // did launch i run the candidate tile (or did igemm_launch reject the hint)?
         std::vector<int> bestc(n, 0);
         int rc = 0;
         // two timed forwards with the hints as they stand; t[i] = the faster of the two for every hinted launch
@@ -90,7 +91,11 @@ struct EngineBase {
             std::fill(t.begin(), t.end(), 1e30f);
             for (int rep = 0; rep < 2 && rc == 0; ++rep) {
                 if (hipEventRecord(ev[0], s) != hipSuccess) rc = -1;
-                for (size_t i = 0; i < n && rc == 0; ++i) { rc = plan[i](s, rows); if (rc == 0 && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = -1; }
+                for (size_t i = 0; i < n && rc == 0; ++i) {
+                    rc = plan[i](s, rows);
+                    if (plan_hint[i]) applied[i] = (char)igemm_last_hint_applied();
+                    if (rc == 0 && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = -1;
+                }
                 if (rc == 0 && hipEventSynchronize(ev[n]) != hipSuccess) rc = -1;
                 for (size_t i = 0; i < n && rc == 0; ++i) {
                     if (!plan_hint[i]) continue;
@@ -106,7 +111,7 @@ struct EngineBase {
             timed_passes();
             for (size_t i = 0; i < n; ++i) {
                 if (c == 0) base[i] = t[i];
-                if (t[i] < best[i]) { best[i] = t[i]; bestc[i] = c; }
+                if (t[i] < best[i] && (c == 0 || applied[i])) { best[i] = t[i]; bestc[i] = c; }      // never pin a config that did not run
             }
         }
         for (size_t i = 0; i < n; ++i)
@@ -129,6 +134,14 @@ struct EngineBase {
     // activation pool, keyed by shape (halo stays zero for ever)
     std::map<std::tuple<int, int, int>, std::vector<half_t*>> pool;
     float* d_gn_stats = nullptr;
+    // fp32 partials of the rule-based K-split igemm launches: owned by the engine (counted in dev_bytes, freed with it) and
+    // allocated while the plan is built - never inside a forward
+    static constexpr long KSPLIT_WS_BYTES = 128L << 20;
+    float* d_ksplit_ws = nullptr;
+    float* ksplit_ws() {
+        if (!d_ksplit_ws) d_ksplit_ws = (float*)dmalloc((size_t)KSPLIT_WS_BYTES, false);
+        return d_ksplit_ws;
+    }
 
     void* dmalloc(size_t bytes, bool zero = true) {
         void* p = nullptr;
@@ -265,8 +278,10 @@ struct Builder {
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // generic igemm op helpers ----------------------------------------------------
-IGemmArgs base_args() {
-    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1; return a;
+IGemmArgs base_args(EngineBase* u = nullptr) {
+    IGemmArgs a; std::memset(&a, 0, sizeof(a)); a.out_scale = 1.0f; a.taps = 1;
+    if (u) { a.ws_buf = u->ksplit_ws(); a.ws_bytes = a.ws_buf ? EngineBase::KSPLIT_WS_BYTES : 0; }
+    return a;
 }
 
 struct Plan {
@@ -277,7 +292,7 @@ struct Plan {
     // conv3x3 on padded NHWC.  amode 1 normal, 2 stride-2 (src is 2H x 2W), 3 upsample (src is H/2 x W/2)
     void conv3x3(const Tensor& src, const Tensor& dst, const half_t* w, const float* bias, int amode,
                  const float* temb, int temb_ld, const Tensor* resid, int ashift = 0) {
-        IGemmArgs a = base_args();
+        IGemmArgs a = base_args(u);
         a.a0 = src.p; a.C0 = src.C; a.taps = 9; a.amode = amode; a.ashift = ashift; a.H = dst.H; a.W = dst.W;
         a.w = w; a.N = dst.C; a.K = 9 * src.C; a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
         a.rows_per_batch = dst.H * dst.W;
@@ -291,7 +306,7 @@ struct Plan {
     }
     // 1x1 conv over (src0 || src1) padded -> padded
     void conv1x1(const Tensor& s0, const Tensor* s1, const Tensor& dst, const half_t* w, const float* bias) {
-        IGemmArgs a = base_args();
+        IGemmArgs a = base_args(u);
         a.a0 = s0.p; a.C0 = s0.C; if (s1) { a.a1 = s1->p; a.C1 = s1->C; }
         a.amode = 1; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = a.C0 + a.C1; a.bias = bias;
         a.rows_per_batch = dst.H * dst.W; a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
@@ -304,7 +319,7 @@ struct Plan {
     // token GEMM: out[M][N] = A[M][K] W^T (+bias)(+resid, may alias out)
     void linear(const half_t* A, int K, half_t* out, int N, const half_t* w, const float* bias, const half_t* resid,
                 int tokens, int epi = EPI_STORE) {
-        IGemmArgs a = base_args();
+        IGemmArgs a = base_args(u);
         a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.bias = bias;
         a.resid = resid; a.rmode = 0; a.rld = N; a.out = out; a.omode = 0;
         a.old = (epi == EPI_GEGLU) ? N / 2 : N; a.epi = epi; a.rows_per_batch = tokens;
@@ -315,7 +330,7 @@ struct Plan {
     }
     // tokens -> padded NHWC with residual from a padded tensor (Transformer2D proj_out)
     void linear_to_padded(const half_t* A, int K, const Tensor& dst, const half_t* w, const float* bias, const Tensor& resid) {
-        IGemmArgs a = base_args();
+        IGemmArgs a = base_args(u);
         a.a0 = A; a.C0 = K; a.amode = 0; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = K; a.bias = bias;
         a.resid = resid.p; a.rmode = 1; a.rld = resid.C; a.out = dst.p; a.omode = 1; a.old = dst.C;
         a.epi = EPI_STORE; a.rows_per_batch = dst.H * dst.W;
@@ -329,7 +344,7 @@ struct Plan {
     void heads(const half_t* A, int K, const half_t* w, int N, int tokens, int part0, int C, int nheads,
                half_t* q, half_t* k, half_t* vt, int q_tok_pad, int tok_pad, bool count = true,
                const float* bias = nullptr) {
-        IGemmArgs a = base_args();
+        IGemmArgs a = base_args(u);
         const int d = C / nheads;
         a.a0 = A; a.C0 = K; a.amode = 0; a.w = w; a.N = N; a.K = K; a.epi = EPI_HEADS;
         a.bias = bias;

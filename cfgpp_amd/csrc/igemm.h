@@ -46,6 +46,8 @@ struct IGemmArgs {
     int n_main;               // tiles [0, n_main) are computed whole by one block each
     int ksplit;               // tiles [n_main, T) are K-split ksplit ways into fp32 partials ...
     float* ws;                // ... in this workspace, finished by igemm_reduce_kernel
+    float* ws_buf;            // the CALLER's K-split workspace (engines own one: allocated at plan-build time, counted in
+    long ws_bytes;            // *_device_bytes(), freed with the engine); null: a process-global per-stream buffer (test wrappers)
     int cfg_hint;             // pinned by the engine's in-situ tuning pass: bits 0-5 tile config (0 = heuristic; 1, 4 .. 12, 14),
                               // bits 6-7 tile walk (0 = by operand bytes, 1 = M-major, 2 = N-major)
     int allow_split;          // 0: never K-split this launch (autotuned launches: keeps results independent of the tile choice)
@@ -63,4 +65,5 @@ struct IGemmArgs {
 
 int igemm_launch(const IGemmArgs& a, hipStream_t stream);
 int igemm_autotune_enabled();
+int igemm_last_hint_applied();     // did the last igemm_launch run the tile its cfg_hint named?
 unsigned igemm_tune_mask();

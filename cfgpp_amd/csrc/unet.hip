@@ -348,7 +348,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
             if (!ck || !cvt || cfgpp_op_attention_prepare_vt(cvt, R * nheads, d, ck_pad, nullptr)) { B.ok = false; B.err = "cross-attention K/V^T allocation failed"; }
             {
                 cfgpp_unet* uu = u; const int Dc = c.cross_attention_dim; const int ckp = ck_pad;
-                IGemmArgs a = base_args();
+                IGemmArgs a = base_args(u);
                 a.C0 = Dc; a.amode = 0; a.w = wkv2; a.N = 2 * C; a.K = Dc; a.epi = EPI_HEADS;
                 a.hq = nullptr; a.hk = ck; a.hvt = cvt; a.part0 = 1; a.part_width = C; a.head_dim = d; a.head_dim_pad = dp;
                 a.heads = nheads; a.tok_pad = ckp; a.q_tok_pad = ckp;

@@ -195,7 +195,7 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
         half_t* wo = B.linear(ap + ".to_out.0.weight"); float* bo = B.f32(ap + ".to_out.0.bias");
         P.groupnorm(y, nullptr, v->tok_a, false, ng, nb, 1e-6f, false);
         {   // QKV projection -> head-major (1 head, d = 512)
-            IGemmArgs a = base_args();
+            IGemmArgs a = base_args(v);
             a.a0 = v->tok_a; a.C0 = C; a.amode = 0; a.w = wqkv; a.N = 3 * C; a.K = C; a.bias = bqkv; a.epi = EPI_HEADS;
             a.rows_per_batch = T; a.hq = v->hq; a.hk = v->hk; a.hvt = v->hvt; a.part0 = 0; a.part_width = C;
             a.head_dim = C; a.head_dim_pad = C; a.heads = 1; a.tok_pad = T; a.q_tok_pad = T;
@@ -208,7 +208,7 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
             cfgpp_vae* vv = v; const float scale = 1.0f / sqrtf((float)C);
             P.ops->push_back([=](hipStream_t s, int rows) {
                 for (int b = 0; b < rows; ++b) {
-                    IGemmArgs a = base_args();
+                    IGemmArgs a = base_args(vv);      // (the engine's K-split workspace exists since the plan was built)
                     a.a0 = vv->hq + (size_t)b * T * C; a.C0 = C; a.amode = 0; a.w = vv->hk + (size_t)b * T * C; a.M = T; a.N = T; a.K = C;
                     a.out = vv->smat + (size_t)b * T * T; a.omode = 0; a.old = T; a.epi = EPI_STORE; a.out_scale = scale; a.rows_per_batch = T;
                     int e = igemm_launch(a, s); if (e) return e;
@@ -220,7 +220,7 @@ int cfgpp_vae_finalize(cfgpp_vae* v) {
             if (tagged) v->tag(2, 0.0, "vae softmax");
             P.ops->push_back([=](hipStream_t s, int rows) {
                 for (int b = 0; b < rows; ++b) {
-                    IGemmArgs a = base_args();
+                    IGemmArgs a = base_args(vv);
                     a.a0 = vv->smat + (size_t)b * T * T; a.C0 = T; a.amode = 0; a.w = vv->hvt + (size_t)b * C * T; a.M = T; a.N = C; a.K = T;
                     a.out = vv->tok_o + (size_t)b * T * C; a.omode = 0; a.old = C; a.epi = EPI_STORE; a.rows_per_batch = T;
                     int e = igemm_launch(a, s); if (e) return e;

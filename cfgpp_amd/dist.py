@@ -124,3 +124,47 @@ def broadcast_ints(values: Optional[Sequence[int]], device, src: int = 0) -> Lis
         buf.copy_(torch.tensor(list(values), dtype=torch.int64))
     dist.broadcast(buf, src=src)
     return [int(v) for v in buf.cpu()]
+
+
+def gather_strings(text: str, device) -> List[str]:
+    """every rank's string on every rank (rank order): the sibling of :func:`gather_floats` for identity records
+    (backend, device name, PCI bus id ...), padded to the longest and sent as bytes in one all_gather."""
+    if not dist.is_initialized():
+        return [text]
+    raw = text.encode("utf-8")
+    n = torch.tensor([len(raw)], dtype=torch.int64, device=device)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    width = int(n.item())
+    buf = torch.zeros(width + 8, dtype=torch.uint8, device=device)
+    buf[:8] = torch.tensor(list(len(raw).to_bytes(8, "little")), dtype=torch.uint8)
+    if raw:
+        buf[8:8 + len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    bufs = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, buf)
+    out = []
+    for b in bufs:
+        b = b.cpu()
+        ln = int.from_bytes(bytes(b[:8].tolist()), "little")
+        out.append(bytes(b[8:8 + ln].tolist()).decode("utf-8"))
+    return out
+
+
+def rank_identity(device) -> str:
+    """one line that says what THIS rank is running on: backend, world size, device name + PCI bus id, RCCL version - gathered
+    into the bench line so that a multi-GPU record shows N distinct GPUs behind N ranks"""
+    import json
+    rec = {"rank": dist.get_rank() if dist.is_initialized() else 0,
+           "world": dist.get_world_size() if dist.is_initialized() else 1,
+           "backend": dist.get_backend() if dist.is_initialized() else "none",
+           "pid": os.getpid(), "device": str(device)}
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        rec["name"] = props.name
+        rec["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+        rec["gcn_arch"] = getattr(props, "gcnArchName", "")
+        try:
+            rec["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rec["rccl_version"] = "unavailable"
+    return json.dumps(rec, sort_keys=True)

@@ -13,7 +13,9 @@ from typing import Optional, Tuple
 import torch
 
 from . import engine as E
+from . import _lib
 from ._lib import CfgppError
+from .tune_cache import PinCache, build_id
 from .unet_config import CONFIGS, UNetConfig
 from .weights import load_safetensors_iter, synth_state_dict_iter
 
@@ -50,6 +52,9 @@ class HipEngine:
             items = weights.items() if isinstance(weights, dict) else weights
         self.unet.load_state_dict(items).finalize()
         self.H, self.W = self.unet.H, self.unet.W
+        # tile pins persist across processes (tune_cache.py): only the first process on a box runs the in-situ tuning passes
+        self._pins = PinCache(getattr(cfg, "name", type(cfg).__name__), (self.H, self.W), torch.cuda.get_device_properties(self.device).name,
+                              build_id(_lib.LIB_PATH), lambda rows: self.unet.export_tuning(rows), lambda h, rows: self.unet.import_tuning(h, rows))
         self._ctx_key = None
         self._eps = None
         # opt-in guard for the first runs with a real checkpoint (real SDXL activations approach the fp16 maximum in the deep
@@ -75,12 +80,14 @@ class HipEngine:
             c = c.expand(B, -1, -1)
         ehs = torch.cat([uc, c], dim=0)
         self.unet.set_context(ehs, text_embeds, time_ids)
+        self._pins.load(2 * B)
         self.B = B
         self._eps = torch.empty((2 * B, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=self.device)
 
     def predict(self, z: torch.Tensor, t: float):
         """(eps_uc, eps_c), each [B,4,H,W] fp16 - replaces predict_noise's UNet call + chunk(2)."""
         eps = self.unet.forward(z, float(t), self._eps)
+        self._pins.save(self.unet.rows)          # (no-op after the first forward at this batch)
         if self.check_finite:
             self._finite_or_raise(t)
         return eps[: self.B], eps[self.B:]

@@ -2,6 +2,7 @@ import os
 import sys
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # as cfgpp_amd/__init__.py (must precede the first HIP call)
+os.environ.setdefault("CFGPP_TUNE_CACHE", "0")           # hermetic tests: no tile pins from / to ~/.cache (test_gpu_unet.py tests the cache itself)
 
 import pytest  # noqa: E402
 

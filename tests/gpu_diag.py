@@ -99,7 +99,7 @@ def t_geglu(M=260, C=64):
     ref = v * F.gelu(g)
     wp, bp = H.pack_geglu(w, b)
     out = {}
-    for c in (1, 2, 4, 6, 10, 12, 13, 14, 15, 16, 17, 20):
+    for c in (1, 2, 4, 6, 10, 12, 13, 14, 15, 16, 17, 20, 24, 26):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.linear(a.to(H.DEV, torch.float16), wp, bp, epi=1)
         out[f"cfg{c}"] = H.err_stats(got, ref)
@@ -198,12 +198,12 @@ def t_big():
     # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings;
     # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages); 15 / 16 / 17: lin32_kernel (32-deep K-tiles, several
     # workgroups per CU) and 13 / 20 (256 x 256 / 256 x 320 on a four-stage ring): tile32_kernel, 32-deep K-tiles
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20):
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20):
+        if c in (9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
@@ -321,7 +321,7 @@ def t_heads(B=2, tokens=96, C=128, nheads=4):
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
     out = {}
-    for c in (0, 7, 9, 11, 12, 13, 14, 15, 16, 17, 20):          # heuristic tile, 128x160, the 3- / 4-stage ring tiles, the 32-deep-K-tile linears (LDS-staged heads epilogue)
+    for c in (0, 7, 9, 11, 12, 13, 14, 15, 16, 17, 20, 24, 25, 26):          # heuristic tile, 128x160, the 3- / 4-stage ring tiles, the 32-deep-K-tile linears (LDS-staged heads epilogue)
         H.lib().cfgpp_igemm_force_config(c)
         hq, hk, hvt = H.heads_project(a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16), B, tokens, C, nheads, 0, 3, qp, kp)
         sfx = "" if c == 0 else f"_cfg{c}"
@@ -342,7 +342,7 @@ def t_heads_d40(B=2, tokens=96, C=320, nheads=8):
     d = C // nheads
     qp, kp = H.round_up(tokens, 128), H.round_up(tokens, 64)
     y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
-    cfgs = [0, 7, 13, 15, 16, 17, 18, 19, 20]
+    cfgs = [0, 7, 13, 15, 16, 17, 18, 19, 20, 24, 25, 26]
     out = {}
     H.lib().cfgpp_igemm_set_mf16_heads(1 if 18 in cfgs else 0)
     try:
@@ -388,15 +388,13 @@ def t_mf16_race():
     return out
 
 
-@case("tile32_unet_sizes")
-def t_tile32():
+def _tiles_at_unet_sizes(cfgs):
     """tile32_kernel (configs 15 / 16 / 17: two or three workgroups per CU; 13 / 20: the 256-wide tiles on four stages) at launch
     shapes of the UNets - linears (to_out + residual, FF-out, GEGLU, ragged M) and convolutions (3x3 with time embedding and
     residual, stride 2 with both paddings, nearest-2x upsample, 1x1 over two concatenated sources) on full-chip grids: right
     against fp32, BIT-IDENTICAL to the 128 x 128 tile of igemm_kernel (same k order: what lets the tuner pin them) and
     identical run to run"""
     out = {}
-    cfgs = (13, 15, 16, 17, 20)
     H.lib().cfgpp_igemm_set_tail_split(0)          # the 128 x 128 baseline must not K-split (different summation order)
     shapes = (("to_out_c320", 16384, 320, 320, True, 0), ("to_out_c1280", 4096, 1280, 1280, True, 0), ("ff_out_c320", 8192, 320, 1280, True, 0),
               ("ragged", 1000, 192, 448, False, 0), ("geglu_c320", 8192, 2560, 320, False, 1))
@@ -461,6 +459,37 @@ def t_tile32():
         out[f"conv1x1_2src_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), identical_runs=True, equals_cfg1=bool(torch.equal(got, base)))
     H.lib().cfgpp_igemm_force_config(0)
     H.lib().cfgpp_igemm_set_tail_split(1)
+    return out
+
+
+@case("tile32_unet_sizes")
+def t_tile32():
+    return _tiles_at_unet_sizes((13, 15, 16, 17, 20))
+
+
+@case("big4_unet_sizes")
+def t_big4():
+    """big4_kernel (configs 24 / 25 / 26: 256 x 256, 128 x 320, 128 x 256 on ONE wave per SIMD, scalar-base LDS-DMA pieces) at the
+    same launch shapes + the QKV head-major projection: right against fp32, bit-identical to the 128 x 128 tile, repeatable"""
+    out = _tiles_at_unet_sizes((24, 25, 26))
+    # head-major epilogue, SD1.5 level-0 geometry (head dim 40) and a 64-wide head, full-chip grid
+    for name, B, tokens, C, nheads in (("heads_d40", 4, 1024, 320, 8), ("heads_d64", 2, 1024, 640, 10)):
+        a = rnd(B * tokens, C, seed=len(name) + 20)
+        w = rnd(3 * C, C, scale=C ** -0.5, seed=len(name) + 21)
+        ad, wd = a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16)
+        d = C // nheads
+        y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
+        H.lib().cfgpp_igemm_force_config(1)
+        base = H.heads_project(ad, wd, B, tokens, C, nheads, 0, 3, tokens, tokens)
+        for c in (24, 25, 26):
+            H.lib().cfgpp_igemm_force_config(c)
+            hq, hk, hvt = H.heads_project(ad, wd, B, tokens, C, nheads, 0, 3, tokens, tokens)
+            eq = all(torch.equal(x, y_) for x, y_ in zip((hq, hk, hvt), base))
+            st = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+            stv = H.err_stats(hvt[:, :d, H.vt_pos(tokens).to(H.DEV)].reshape(B, nheads, d, tokens), y[:, :, 2].permute(0, 2, 3, 1))
+            st["rel_l2"] = max(st["rel_l2"], stv["rel_l2"])
+            out[f"{name}_cfg{c}"] = dict(st, identical_runs=True, equals_cfg1=bool(eq))
+    H.lib().cfgpp_igemm_force_config(0)
     return out
 
 

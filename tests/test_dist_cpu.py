@@ -158,6 +158,29 @@ def test_bench_gpus2_self_launches_two_ranks():
     assert r["config"]["global_batch"] == 2 * r["config"]["per_gpu_batch"]
     assert len(r["ranks"]["job_ms_mean_per_rank"]) == 2
     assert "3 pins broadcast" in r["ranks"]["tile_tuning"]
+    ident = r["ranks"]["identity"]                 # one record per rank: a SCALE line can show that N ranks really ran
+    assert [i["rank"] for i in ident] == [0, 1] and all(i["world"] == 2 and i["backend"] == "gloo" for i in ident)
+    assert len({i["pid"] for i in ident}) == 2
+
+
+def test_bench_global_batch_is_strong_scaling():
+    """--global-batch G (BASELINE configs 3 - 5 are GLOBAL batches): G / N chains per rank, labelled "strong"; a G that does not
+    divide over the ranks, or combined with the per-GPU --batch, is refused"""
+    import json
+    common = ["--steps", "1", "--warmup", "0", "--config", "mock", "--no-profile", "--no-cpu-baseline", "--no-also"]
+    p = _run_mock_bench(["--gpus", "2", "--global-batch", "4"] + common)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
+    assert r["config"]["global_batch"] == 4 and r["config"]["per_gpu_batch"] == 2
+    p1 = _run_mock_bench(["--gpus", "1", "--global-batch", "4"] + common)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    r1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert r1["scaling"] == "strong" and r1["config"]["global_batch"] == 4 and r1["config"]["per_gpu_batch"] == 4
+    bad = _run_mock_bench(["--gpus", "2", "--global-batch", "3"] + common)
+    assert bad.returncode != 0 and "does not divide" in (bad.stderr + bad.stdout)
+    both = _run_mock_bench(["--gpus", "1", "--global-batch", "4", "--batch", "2"] + common)
+    assert both.returncode != 0 and "exclude each other" in (both.stderr + both.stdout)
 
 
 def test_bench_world_size_mismatch_is_an_error():

@@ -125,6 +125,15 @@ def test_32_deep_k_tiles(diag):
     assert not bad, bad
 
 
+def test_one_wave_per_simd_tiles(diag):
+    """big4_kernel (256 x 256 / 128 x 320 / 128 x 256 on four waves) at the UNets' launch shapes, every epilogue: parity vs fp32,
+    bit-identical to the 128 x 128 igemm tile (the tuner may pin it), repeatable"""
+    r = _check(diag, diag.t_big4, "big4_unet_sizes")
+    bad = {k: (v["identical_runs"], v["equals_cfg1"], v.get("halo_zero", True)) for k, v in r.items()
+           if not (v["identical_runs"] and v["equals_cfg1"] and v.get("halo_zero", True))}
+    assert not bad, bad
+
+
 def test_conv_in_out(diag):
     _check(diag, diag.t_cio, "conv_in_out")
 

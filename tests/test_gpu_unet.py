@@ -1,6 +1,7 @@
 """-m gpu: the HIP UNet and the whole sampling loop against the fp32 CPU oracle on identical
 seeds.  Stated tolerance (fp16 storage, fp32 accumulate; measured: a single forward lands at rel-L2 1.0e-3,
 chains at 4e-4 .. 6e-3): per-forward eps rel-L2 <= 2.5e-3, chain tolerances per case (profiles/r02/parity_r02.jsonl)."""
+import os
 import types
 
 import pytest
@@ -125,7 +126,7 @@ def test_unet_output_does_not_depend_on_tile_tuning():
     outs = []
     try:
         lib.cfgpp_igemm_set_tail_split(0)
-        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14)):
+        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14), (0, 24), (0, 25), (0, 26)):
             lib.cfgpp_igemm_set_autotune(tune)
             lib.cfgpp_igemm_force_config(force)
             net = HipUNet(cfg, 8, (32, 32))
@@ -166,6 +167,33 @@ def test_unet_output_same_with_tuning_on_and_off_including_split_launches():
     finally:
         lib.cfgpp_igemm_set_autotune(1)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_tile_pins_persist_across_engines(monkeypatch, tmp_path):
+    """cfgpp_amd/tune_cache.py on the real engine: the first HipEngine tunes on its first forward and writes the pins, a second one
+    (a stand-in for the next process) imports them before its first forward - same pins, bit-identical output, one file"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from cfgpp_amd.hip_engine import HipEngine
+    from cfgpp_amd.unet_config import TINY_SD as cfg
+    monkeypatch.setenv("CFGPP_TUNE_CACHE", str(tmp_path))
+    g = torch.Generator().manual_seed(5)
+    uc = (torch.randn(1, 77, cfg.cross_attention_dim, generator=g) * 0.5).half().cuda()
+    c = (torch.randn(4, 77, cfg.cross_attention_dim, generator=g) * 0.5).half().cuda()
+    z = torch.randn(4, 4, 32, 32, generator=g).cuda()
+    outs, pins = [], []
+    for i in range(2):
+        eng = HipEngine(cfg, max_batch=4, latent_hw=(32, 32))
+        eng.set_context(uc, c)
+        if i == 1:
+            assert eng.export_tuning() == pins[0]          # installed BEFORE the first forward: nothing left to tune
+        eu, ec = eng.predict(z, 400.0)
+        outs.append(torch.cat([eu, ec]).clone())
+        pins.append(eng.export_tuning())
+        del eng
+    files = [f for f in os.listdir(tmp_path) if f.startswith("tune_")]
+    assert len(files) == 1 and "_r8_" in files[0], files
+    assert pins[0] == pins[1] and torch.equal(outs[0], outs[1])
 
 
 def test_check_finite_guard_names_the_timestep(monkeypatch):
