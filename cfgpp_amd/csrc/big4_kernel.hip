@@ -172,11 +172,12 @@ big4_kernel(const IGemmArgs p) {
     // of tile kt+1 overwrite), then NM MFMAs.  Placement is pinned (sched_barrier): after the FIRST MFMA of a 16-deep step the
     // next step's fragments are requested (they have MT * NT - 1 MFMAs to land); the next tile's scalar bases are computed under
     // the first step; its pieces go out one per gap, after every (SPAN / NP)-th MFMA.
-    auto tile = [&](auto more_c, int stage) {
+    auto tile = [&](auto more_c, int stage, bool first) {
         constexpr bool MORE = decltype(more_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (first) tl_stamp(p.tl, 1);
         const char* st = smem + stage * STAGE_BYTES;
         half8_t xa[2][MT], wb[2][NT];
 #pragma unroll
@@ -215,11 +216,11 @@ big4_kernel(const IGemmArgs p) {
     using T_ = std::integral_constant<bool, true>; using F_ = std::integral_constant<bool, false>;
     int stage = 0;
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        tile(T_{}, stage);
+        tile(T_{}, stage, kt == 0);
         if (kt == 0) tl_stamp(p.tl, 7);
         stage ^= 1;
     }
-    tile(F_{}, stage);
+    tile(F_{}, stage, nk == 1);
     __syncthreads();                                           // every wave is done with the ring: LDS is free for the epilogue's staging
     tl_stamp(p.tl, 2);
 

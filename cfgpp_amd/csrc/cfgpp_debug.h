@@ -105,7 +105,8 @@ void cfgpp_igemm_set_big_split(int min_kt);
  * result does not depend on it */
 void cfgpp_igemm_set_n_major(int mode);
 /* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 26; 24 - 26 = the one-wave-per-SIMD tiles of
- * big4_kernel.hip), bit 31 = the tile-walk stage runs (default: all) */
+ * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf8ffffff: everything but 24 - 26, which were never pinned when
+ * offered (profiles/r05/ab/) */
 void cfgpp_igemm_set_tune_mask(unsigned mask);
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins

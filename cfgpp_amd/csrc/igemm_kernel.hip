@@ -1466,7 +1466,12 @@ extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0;
 static int g_big_split_min_kt = 0;
 extern "C" void cfgpp_igemm_set_big_split(int min_kt) { g_big_split_min_kt = min_kt > 0 ? min_kt : 0; }
 int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_staging != 0; }
-static unsigned g_tune_mask = 0xffffffffu;   // bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs
+// bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs.  Default: everything but 24 - 26 (big4_kernel.hip) - measured
+// in situ on the MI355X (profiles/r05/ab/): forced per launch they are slower than the tuned plan on every launch of the SD1.5 /
+// SDXL forwards at the bench batches, and offered to the tuner they are never pinned (the 256 x 256 K loop does reach 0.75 - 0.80 of
+// the matrix peak, but no launch with N = k * 320 fits the tile, and four waves take twice as long over the epilogue as eight), so
+// the three extra candidates would only lengthen the tuning passes.  cfgpp_igemm_set_tune_mask(0xffffffff) offers them.
+static unsigned g_tune_mask = 0xf8ffffffu;
 extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
 unsigned igemm_tune_mask() { return g_tune_mask; }
 
