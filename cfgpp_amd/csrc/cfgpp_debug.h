@@ -104,9 +104,9 @@ void cfgpp_igemm_set_big_split(int min_kt);
 /* tile walk of the implicit GEMM: -1 (default) by operand bytes / the tuner's pin, 0 always M-major, 1 always N-major; the
  * result does not depend on it */
 void cfgpp_igemm_set_n_major(int mode);
-/* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 26; 24 - 26 = the one-wave-per-SIMD tiles of
- * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf8ffffff: everything but 24 - 26, which were never pinned when
- * offered (profiles/r05/ab/) */
+/* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 27; 24 - 26 = the one-wave-per-SIMD tiles of
+ * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf1ffffff: everything but 25 / 26 / 27, which lose in situ
+ * (profiles/r05/ab/) */
 void cfgpp_igemm_set_tune_mask(unsigned mask);
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins

@@ -1426,6 +1426,12 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 16: return launch_tile32<2, 2, 64, 64, 3, 3>(a, stream);      // 128 x 128, 4 waves, 48 KB: 3 / CU
         case 17: return launch_tile32<4, 1, 64, 64, 3, 2>(a, stream);      // 256 x 64, 4 waves, 60 KB: 2 / CU
         case 13: return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);     // 256 x 256, 8 waves, 128 KB
+        // 128 x 320 as FOUR waves of 64 x 160 on a two-stage 32-deep ring (65 KB): TWO workgroups per CU, i.e. the 256 x 320 tile of
+        // config 5 (same wave tiles, same LDS traffic per CU) cut into two halves that no longer share a barrier - while one half
+        // waits for its tile or sits in its epilogue, the other half's waves have the matrix pipes (round 5).  Plain stores only
+        // (ten accumulator tiles per wave: no staged head-major epilogue, no GEGLU pairs).
+        case 27: if (a.epi != EPI_STORE) return launch_tile32<2, 2, 64, 64, 3, 3>(a, stream);
+                 return launch_tile32<2, 2, 64, 160, 2, 2>(a, stream);
         case 20: if (a.epi == EPI_GEGLU) return launch_tile32<2, 4, 128, 64, 4, 2>(a, stream);       // (GEGLU needs 64-wide wave tiles)
                  return launch_tile32<4, 2, 64, 160, 4, 2>(a, stream);     // 256 x 320, 8 waves, 147 KB
         // 128 x 160 as 8 waves of 32 x 80 on the 16x16x32 MFMA, 3 / 4 LDS stages (igemm16_kernel): plain-store launches with
@@ -1466,12 +1472,14 @@ extern "C" void cfgpp_igemm_force_split(int s) { g_force_split = s >= 2 ? s : 0;
 static int g_big_split_min_kt = 0;
 extern "C" void cfgpp_igemm_set_big_split(int min_kt) { g_big_split_min_kt = min_kt > 0 ? min_kt : 0; }
 int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_staging != 0; }
-// bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs.  Default: everything but 24 - 26 (big4_kernel.hip) - measured
+// bit c: the tuner may pin tile config c; bit 31: the tile-walk stage runs.  Default: everything but 25 / 26 (big4_kernel.hip: 128 x 320 / 128 x 256 on four waves) and 27 (128 x 320 as two workgroups per CU) - measured
 // in situ on the MI355X (profiles/r05/ab/): forced per launch they are slower than the tuned plan on every launch of the SD1.5 /
 // SDXL forwards at the bench batches, and offered to the tuner they are never pinned (the 256 x 256 K loop does reach 0.75 - 0.80 of
 // the matrix peak, but no launch with N = k * 320 fits the tile, and four waves take twice as long over the epilogue as eight), so
-// the three extra candidates would only lengthen the tuning passes.  cfgpp_igemm_set_tune_mask(0xffffffff) offers them.
-static unsigned g_tune_mask = 0xf8ffffffu;
+// they would only lengthen the tuning passes (27: 11 - 14 % slower than the 8-wave 256 x 320 tile on the 64x64-level convolutions it
+// was built for, profiles/r05/ab/forced_hint27_*); the 256 x 256 one (24) stays a candidate because the VAE decoder's N = 256 / 512 convolutions
+// do take it (+8 % on those launches, decode -2.5 %: profiles/r05/ab/vae_big4_call7.txt).  cfgpp_igemm_set_tune_mask(0xffffffff) offers all.
+static unsigned g_tune_mask = 0xf1ffffffu;
 extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
 unsigned igemm_tune_mask() { return g_tune_mask; }
 
@@ -1561,7 +1569,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
-                            h == 13 || h == 15 || h == 16 || h == 17 || (h == 20 && a.epi != EPI_GEGLU) || ((h >= 24 && h <= 26) && big4_ok(h, a))) && (g_big_tiles || h == 1);
+                            h == 13 || h == 15 || h == 16 || h == 17 || (h == 20 && a.epi != EPI_GEGLU) || (h == 27 && a.epi == EPI_STORE) || ((h >= 24 && h <= 26) && big4_ok(h, a))) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; g_last_hint_applied = 1; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

@@ -198,12 +198,12 @@ def t_big():
     # 7 / 8: 128x160 / 128x320; 10: 256x320 with the waves stacked along M; 9 / 11 / 12 / 14: 3- and 4-stage LDS rings;
     # 18 / 19: 128x160 as 8 waves on the 16x16x32 MFMA (3 / 4 stages); 15 / 16 / 17: lin32_kernel (32-deep K-tiles, several
     # workgroups per CU) and 13 / 20 (256 x 256 / 256 x 320 on a four-stage ring): tile32_kernel, 32-deep K-tiles
-    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26):
+    for c in (4, 5, 6, 7, 8, 10, 9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26, 27):
         H.lib().cfgpp_igemm_force_config(c)
         got = H.conv3x3(H.to_pn(x), H.pack_conv3(w), b.to(H.DEV), 24, 20, 1, temb.to(H.DEV), 320, H.to_pn(res))
         out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got))
         out[f"linear_cfg{c}"] = H.err_stats(H.linear(a.to(H.DEV, torch.float16), wl.to(H.DEV, torch.float16), bl.to(H.DEV)), refl)
-        if c in (9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26):
+        if c in (9, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 24, 25, 26, 27):
             for K, ak, wk, rk in shortk:
                 out[f"linear_k{K}_cfg{c}"] = H.err_stats(H.linear(ak.to(H.DEV, torch.float16), wk.to(H.DEV, torch.float16)), rk)
     H.lib().cfgpp_igemm_force_config(0)
@@ -464,7 +464,7 @@ def _tiles_at_unet_sizes(cfgs):
 
 @case("tile32_unet_sizes")
 def t_tile32():
-    return _tiles_at_unet_sizes((13, 15, 16, 17, 20))
+    return _tiles_at_unet_sizes((13, 15, 16, 17, 20, 27))
 
 
 @case("big4_unet_sizes")

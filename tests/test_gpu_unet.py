@@ -126,7 +126,7 @@ def test_unet_output_does_not_depend_on_tile_tuning():
     outs = []
     try:
         lib.cfgpp_igemm_set_tail_split(0)
-        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14), (0, 24), (0, 25), (0, 26)):
+        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14), (0, 24), (0, 25), (0, 26), (0, 27)):
             lib.cfgpp_igemm_set_autotune(tune)
             lib.cfgpp_igemm_force_config(force)
             net = HipUNet(cfg, 8, (32, 32))
