@@ -81,6 +81,11 @@ DEBUG_PROTOTYPES = {
     "cfgpp_op_softmax_rows": (_I, [_P, _L, _I, _P]),
     "cfgpp_op_conv_in_ex": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     "cfgpp_op_groupnorm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cfgpp_op_groupnorm_pre": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "cfgpp_op_igemm_set_gstat": (None, [_P]),
+    "cfgpp_op_igemm_gstat_written": (_I, []),
+    "cfgpp_groupnorm_set_prestats": (None, [_I]),
+    "cfgpp_groupnorm_prestats_enabled": (_I, []),
     "cfgpp_op_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "cfgpp_op_attention_prepare_vt": (_I, [_P, _I, _I, _I, _P]),
     "cfgpp_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

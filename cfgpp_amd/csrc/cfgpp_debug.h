@@ -19,6 +19,19 @@ int cfgpp_op_conv_in_ex(const void* z, int z_is_half, void* out, const float* w,
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
                        float* stats, int N, int H, int W, int C0, int C1, int G, float eps, int silu,
                        int dst_padded, void* stream);
+/* GroupNorm with the statistics taken from the PRODUCERS of src0 / src1 (round 5): gst0 / gst1 = [N*H*W / 32][C0 or C1][2] fp32
+ * {mean, M2} per 32-pixel block and channel, written by the LDS-staged store epilogues of the implicit GEMM (IGemmArgs::gstat);
+ * a finalize launch (N x G workgroups, Chan's parallel variance in a fixed order) + the apply launch.  stats: >= N*G*2 floats. */
+int cfgpp_op_groupnorm_pre(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
+                           const float* gst0, const float* gst1, float* stats, int N, int H, int W, int C0, int C1, int G,
+                           float eps, int silu, int dst_padded, void* stream);
+/* test hook: the next cfgpp_op_igemm launches write those statistics of their output into buf (NULL = off);
+ * cfgpp_op_igemm_gstat_written(): did the last one (0 for K-split launches / generic epilogues)? */
+void cfgpp_op_igemm_set_gstat(void* buf);
+int cfgpp_op_igemm_gstat_written(void);
+/* 1 (default): the engines' GroupNorms take the producers' statistics whenever the producer wrote them; 0: always their own pass (A/B) */
+void cfgpp_groupnorm_set_prestats(int on);
+int cfgpp_groupnorm_prestats_enabled(void);
 /* development / A-B switch of the GroupNorm form: 0 auto, 1 always the two-launch form, 2 the one-launch
  * slab-in-registers kernel whenever the slab fits (csrc/norm_kernels.hip). */
 void cfgpp_groupnorm_set_mode(int mode);

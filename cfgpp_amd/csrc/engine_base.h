@@ -30,6 +30,12 @@ struct HostParam {
 struct Tensor {   // halo-padded NHWC fp16 activation
     half_t* p = nullptr;
     int H = 0, W = 0, C = 0;
+    // GroupNorm statistics of this tensor as its PRODUCER left them (IGemmArgs::gstat: [rows * H * W / 32][C][2] fp32), pooled with
+    // the activation buffer; *gst_ok (host, one per acquired tensor = per producer in the plan) is set by the producer's igemm_launch
+    // on every forward: 1 = the buffer holds this forward's statistics, 0 = the producer could not write them (K-split launch,
+    // non-igemm producer: never set) and the consumer runs its own statistics pass.  Null on maps under 16 x 16 pixels.
+    float* gst = nullptr;
+    int* gst_ok = nullptr;
 };
 
 using Op = std::function<int(hipStream_t, int /*rows*/)>;
@@ -131,8 +137,9 @@ struct EngineBase {
         tuned_rows = rows;
         return rc;
     }
-    // activation pool, keyed by shape (halo stays zero for ever)
-    std::map<std::tuple<int, int, int>, std::vector<half_t*>> pool;
+    // activation pool, keyed by shape (halo stays zero for ever); every buffer travels with its statistics buffer
+    std::map<std::tuple<int, int, int>, std::vector<std::pair<half_t*, float*>>> pool;
+    std::deque<int> gst_flags;      // one "producer wrote statistics" flag per acquired tensor
     float* d_gn_stats = nullptr;
     // fp32 partials of the rule-based K-split igemm launches: owned by the engine (counted in dev_bytes, freed with it) and
     // allocated while the plan is built - never inside a forward
@@ -155,11 +162,15 @@ struct EngineBase {
         auto key = std::make_tuple(H, W, C);
         auto& fl = pool[key];
         Tensor t; t.H = H; t.W = W; t.C = C;
-        if (!fl.empty()) { t.p = fl.back(); fl.pop_back(); return t; }
+        gst_flags.push_back(0);
+        t.gst_ok = &gst_flags.back();
+        if (!fl.empty()) { t.p = fl.back().first; t.gst = fl.back().second; fl.pop_back(); return t; }
         t.p = (half_t*)dmalloc((size_t)max_rows * (H + 2) * (W + 2) * C * sizeof(half_t));
+        if (H * W >= 256 && (H * W) % 32 == 0 && C % 8 == 0)
+            t.gst = (float*)dmalloc((size_t)max_rows * (H * W / 32) * C * 2 * sizeof(float), false);
         return t;
     }
-    void rel(const Tensor& t) { if (t.p) pool[std::make_tuple(t.H, t.W, t.C)].push_back(t.p); }
+    void rel(const Tensor& t) { if (t.p) pool[std::make_tuple(t.H, t.W, t.C)].push_back(std::make_pair(t.p, t.gst)); }
     ~EngineBase() { for (void* p : allocs) hipFree(p); }
 };
 
@@ -298,6 +309,7 @@ struct Plan {
         a.rows_per_batch = dst.H * dst.W;
         if (resid) { a.resid = resid->p; a.rmode = 1; a.rld = resid->C; }
         a.out = dst.p; a.omode = 1; a.old = dst.C; a.epi = EPI_STORE;
+        a.gstat = dst.gst; a.stat_flag = dst.gst ? dst.gst_ok : nullptr;      // the consumer GroupNorm takes its statistics from this epilogue
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * 9.0 * src.C;
         int* hint = u->new_hint(ops == &u->plan);
@@ -334,6 +346,7 @@ struct Plan {
         a.a0 = A; a.C0 = K; a.amode = 0; a.H = dst.H; a.W = dst.W; a.w = w; a.N = dst.C; a.K = K; a.bias = bias;
         a.resid = resid.p; a.rmode = 1; a.rld = resid.C; a.out = dst.p; a.omode = 1; a.old = dst.C;
         a.epi = EPI_STORE; a.rows_per_batch = dst.H * dst.W;
+        a.gstat = dst.gst; a.stat_flag = dst.gst ? dst.gst_ok : nullptr;
         const int HW = dst.H * dst.W;
         u->macs_per_row += (double)HW * dst.C * K;
         int* hint = u->new_hint(ops == &u->plan);
@@ -360,7 +373,14 @@ struct Plan {
         EngineBase* uu = u;
         const half_t* p0 = s0.p; const half_t* p1 = s1 ? s1->p : nullptr;
         const int H = s0.H, W = s0.W, C0 = s0.C, C1 = s1 ? s1->C : 0, G = u->norm_groups;
+        const float* gst0 = s0.gst; const float* gst1 = s1 ? s1->gst : nullptr;
+        const int* ok0 = s0.gst_ok; const int* ok1 = s1 ? s1->gst_ok : nullptr;
         ops->push_back([=](hipStream_t s, int rows) {
+            // statistics from the producers' epilogues when every source's producer wrote them on THIS forward (a host flag each
+            // igemm_launch sets); otherwise this op's own statistics pass
+            if (cfgpp_groupnorm_prestats_enabled() && gst0 && ok0 && *ok0 && (!p1 || (gst1 && ok1 && *ok1)))
+                return cfgpp_op_groupnorm_pre(p0, p1, dst, g, b, gst0, gst1, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
+                                              dst_padded ? 1 : 0, s);
             return cfgpp_op_groupnorm(p0, p1, dst, g, b, uu->d_gn_stats, rows, H, W, C0, C1, G, eps, silu ? 1 : 0,
                                       dst_padded ? 1 : 0, s);
         });

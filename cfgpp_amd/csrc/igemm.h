@@ -33,6 +33,14 @@ struct IGemmArgs {
     half_t* out;
     int omode, old;           // output row map: 0 linear, 1 padded
     float out_scale;          // multiplies acc before bias (1.0 normally)
+    // GroupNorm statistics of the OUTPUT, written by the LDS-staged plain-store epilogues (round 5): per 32-row block and output
+    // column the pair (mean, sum of squared deviations) of the fp16 values actually stored (after bias / time embedding /
+    // residual), gstat[(m / 32) * N + n] = {mean, M2} - fixed arithmetic per block and column, so the pairs do not depend on the
+    // tile config.  A consumer GroupNorm combines them (cfgpp_op_groupnorm_pre) instead of re-reading the tensor.  Null: off.
+    // *stat_flag (HOST memory) is set by igemm_launch to 1 when the launch it issued writes them, 0 when it does not (K-split
+    // launches, generic epilogues): the consumer falls back to its own statistics pass then.
+    float* gstat;
+    int* stat_flag;
     // EPI_HEADS
     half_t* hq; half_t* hk; half_t* hvt;
     int part0;                // which part column 0 belongs to: 0=Q, 1=K (K,V projection)

@@ -236,6 +236,33 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& p, f32x16 (&acc)
     }
 }
 
+// GroupNorm statistics of one staged 32-row block (IGemmArgs::gstat): lane cp takes the column pair (2 cp, 2 cp + 1) of the
+// wave's WTN-column slab in LDS (fp16, the values that were just stored), pivot = the pair's values in row 0, rows 1 .. 31 in
+// order: (mean, M2) per column, written as one float4 per pair.  The arithmetic per (block, column) is the same whatever tile
+// config staged the block, so the statistics - like the outputs - do not depend on tile tuning.
+template <int WTN, int PITCH>
+__device__ __forceinline__ void gstat_block(const IGemmArgs& p, const char* stg, int m_blk0, int nw0, int lane) {
+    if (m_blk0 >= p.M) return;
+    float* dst = p.gstat + ((long)(m_blk0 >> 5) * p.N + nw0) * 2;
+    // (rolled loops on purpose: unrolled, the 31 LDS reads of a pass are hoisted into 31 more live registers, which the tiles that
+    //  sit at their register budget - 64 x 160 waves at 243 of 256, the four-waves-per-SIMD 256 x 128 tile at 126 of 128 - spill)
+#pragma unroll 1
+    for (int cp = lane; cp < WTN / 2; cp += 64) {
+        const half2_t x0 = *reinterpret_cast<const half2_t*>(stg + cp * 4);
+        const float pv0 = (float)x0[0], pv1 = (float)x0[1];
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll 4
+        for (int r = 1; r < 32; ++r) {
+            const half2_t x = *reinterpret_cast<const half2_t*>(stg + r * PITCH + cp * 4);
+            const float d0 = (float)x[0] - pv0, d1 = (float)x[1] - pv1;
+            s0 += d0; q0 += d0 * d0; s1 += d1; q1 += d1 * d1;
+        }
+        if (nw0 + 2 * cp < p.N)
+            *reinterpret_cast<float4*>(dst + 4 * cp) = make_float4(pv0 + s0 * (1.0f / 32.0f), q0 - s0 * s0 * (1.0f / 32.0f),
+                                                                   pv1 + s1 * (1.0f / 32.0f), q1 - s1 * s1 * (1.0f / 32.0f));
+    }
+}
+
 // EPI_STORE through LDS: the MFMA accumulator layout gives each lane 4 consecutive features of ONE row,
 // i.e. 8-byte stores scattered over 32 rows per instruction (and the same pattern for the residual
 // read).  Here each wave transposes its 32 x WTN slab through a private LDS region and then moves whole
@@ -316,9 +343,11 @@ __device__ __forceinline__ void igemm_epilogue_staged(const IGemmArgs& p, f32x16
             if (p.resid) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
+                if (p.gstat && c < 32 * CPR) *reinterpret_cast<half8_t*>(stg + (r & 31) * PITCH + cc * 16) = v;      // the stored value, for the statistics below
             }
             if (c < 32 * CPR && mm < p.M && n < p.N) *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
         }
+        if (p.gstat) gstat_block<WTN, PITCH>(p, stg, mw0 + i * 32, nw0, lane);
     }
 }
 

@@ -861,9 +861,11 @@ __device__ __forceinline__ void igemm_epilogue_staged16(const IGemmArgs& p, f32x
         if (p.resid) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = (half_t)((float)v[k] + (float)rres[q][k]);
+            if (p.gstat && c < 32 * CPR) *reinterpret_cast<half8_t*>(stg + (r & 31) * PITCH + cc * 16) = v;
         }
         if (c < 32 * CPR && mm < p.M && n < p.N) *reinterpret_cast<half8_t*>(p.out + (long)op * p.old + n) = v;
     }
+    if (p.gstat) gstat_block<WTN, PITCH>(p, stg, mw0, nw0, lane);
 }
 
 // EPI_HEADS for the 16 x 16 accumulator layout: the wave's 32-token x 80-column slab goes through LDS as five
@@ -1196,6 +1198,15 @@ static int par_slots(const IGemmArgs& a, int BM) {
     return span < nbatch ? span : nbatch;
 }
 
+// GroupNorm statistics of the output (IGemmArgs::gstat): only the LDS-staged plain-store epilogues of whole-K tiles write them.
+// Decided HERE, per launch, and reported to the caller through *stat_flag (host memory): a consumer must not trust a buffer the
+// launch did not fill.
+static void stats_decide(IGemmArgs& a, bool staged_store) {
+    const bool on = a.gstat != nullptr && staged_store && a.epi == EPI_STORE && (a.N & 7) == 0 && (a.M & 31) == 0 && a.ksplit <= 1 && a.n_main > 0;
+    if (!on) a.gstat = nullptr;
+    if (a.stat_flag) *a.stat_flag = on ? 1 : 0;
+}
+
 template <int WM, int WN, int WTM, int WTN, bool GLDS, int AMODE, int NST = 2>
 int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     constexpr int BM = WM * WTM, BN = WN * WTN, NTHR = 64 * WM * WN;
@@ -1247,6 +1258,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
         }
     }
     const int n_tail = T - a.n_main;
+    stats_decide(a, WM * WN * 32 * (WTN * 2 + 16) <= NST * (BM + BN) * 128 && a.staged_epi && n_tail == 0);
     if (n_tail > 0) a.n_major = 0;                     // K-split tiles keep the M-major numbering the reduce kernel uses
     a.walk_div = a.n_major ? cdiv(a.M, BM) : cdiv(a.N, BN);
     a.tl = tl_take(WM * 100 + WN * 10 + (GLDS ? 1 : 0), a.n_main + n_tail * a.ksplit, NTHR, BM, BN, NST, a);
@@ -1297,6 +1309,7 @@ int launch_tile32_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    stats_decide(a, NTHR / 64 * 32 * (WTN * 2 + 16) <= NST * (BM + BN) * 64 && a.staged_epi);
     a.tl = tl_take(3200 + WM * 100 + WN * 10, a.n_main, NTHR, BM, BN, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(NTHR), smem, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
@@ -1345,6 +1358,7 @@ int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    stats_decide(a, true);
     a.tl = tl_take(16, a.n_main, 512, 128, 160, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(512), smem, stream, a);
     CFGPP_HIP_CHECK(hipGetLastError());
@@ -1379,6 +1393,7 @@ static int launch_big4(int cfg, const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    stats_decide(a, true);
     a.tl = tl_take(4000 + cfg, a.n_main, 256, BM, BN, 2, a);
     return big4_run(cfg, a, a.n_main, smem, stream);
 }

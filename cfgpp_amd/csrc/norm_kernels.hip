@@ -40,6 +40,10 @@ struct GNArgs {
     int pix_per_block;
     int dst_padded;       // 1: dst is halo-padded NHWC, 0: dst is token-major [N*H*W][C]
     int gs;               // slab kernel: groups per workgroup
+    // statistics from the PRODUCERS of src0 / src1 (igemm epilogues, IGemmArgs::gstat): per 32-pixel block and channel {mean, M2};
+    // gn_finalize_kernel folds them into stats[(n * G + g) * 2] = {mean, rstd}, which gn_apply_kernel then takes as given (pre = 1)
+    const float* gst0; const float* gst1;
+    int pre;
 };
 
 __device__ __forceinline__ long pad_off(int n, int y, int x, int H, int W) {
@@ -261,6 +265,52 @@ gn_stats_kernel(GNArgs a) {
     }
 }
 
+// Statistics from the producers (round 5): the convolution / projection that wrote src0 (and src1) left, per 32-pixel block and
+// channel, the pair {mean, M2 = sum of squared deviations from that mean} of the fp16 values it stored (igemm_device.h,
+// gstat_block).  One workgroup per (group, sample) folds the cpg x (H*W / 32) pairs of its group with the parallel-variance
+// (Chan) update - every pair carries 32 elements - in a FIXED order: thread t takes pairs t, t + 256, ... sequentially, then a
+// binary tree over the 256 threads.  No E[x^2] - mean^2 anywhere, so |mean| >> sigma is harmless, and no second pass over the tensor.
+struct GnAcc { float n, mean, m2; };
+__device__ __forceinline__ void gn_acc_merge(GnAcc& a, const GnAcc& b) {
+    if (b.n == 0.f) return;
+    if (a.n == 0.f) { a = b; return; }
+    const float n = a.n + b.n, d = b.mean - a.mean;
+    a.mean += d * (b.n / n);
+    a.m2 += b.m2 + d * d * (a.n * b.n / n);
+    a.n = n;
+}
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(GNArgs a) {
+    __shared__ GnAcc s_acc[256];
+    const int C = a.C0 + a.C1, cpg = C / a.G;
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int nb = (a.H * a.W) >> 5;                       // 32-pixel blocks per sample (H * W % 32 == 0, checked by the launcher)
+    const long P = (long)cpg * nb;
+    GnAcc acc = {0.f, 0.f, 0.f};
+    for (long i = tid; i < P; i += 256) {
+        const int b = (int)(i / cpg), cl = (int)(i - (long)b * cpg);
+        const int c = g * cpg + cl;
+        const float* gst; int cs, Cs;
+        if (c < a.C0) { gst = a.gst0; cs = c; Cs = a.C0; } else { gst = a.gst1; cs = c - a.C0; Cs = a.C1; }
+        const float2 pr = *reinterpret_cast<const float2*>(gst + (((long)n * nb + b) * Cs + cs) * 2);
+        const GnAcc e = {32.f, pr.x, pr.y};
+        gn_acc_merge(acc, e);
+    }
+    s_acc[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { GnAcc x = s_acc[tid]; gn_acc_merge(x, s_acc[tid + o]); s_acc[tid] = x; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const GnAcc t = s_acc[0];
+        float var = t.m2 / t.n;
+        var = var < 0.f ? 0.f : var;
+        float* dst = a.stats + ((long)n * a.G + g) * 2;
+        dst[0] = t.mean; dst[1] = rsqrtf(var + a.eps);
+    }
+}
+
 // Pass 2: apply.  Prologue: the fixed-order reduction of the nblk (<= 256) stats blocks to (mean, rstd) per group,
 // recomputed by every workgroup (16 .. 64 KB of L2 reads).
 __global__ void __launch_bounds__(256)
@@ -273,7 +323,12 @@ gn_apply_kernel(GNArgs a) {
     const int HW = a.H * a.W;
     const int p0 = blockIdx.x * a.pix_per_block;
     const int p1 = min(p0 + a.pix_per_block, HW);
-    {
+    if (a.pre) {                                                     // (mean, rstd) per group were finalised by gn_finalize_kernel
+        if ((int)threadIdx.x < a.G) {
+            const float2 mr = *reinterpret_cast<const float2*>(a.stats + ((long)n * a.G + threadIdx.x) * 2);
+            s_mean[threadIdx.x] = mr.x; s_rstd[threadIdx.x] = mr.y;
+        }
+    } else {
         // thread (g = t % G, slice = t / G) sums stats blocks slice, slice + NSL, ... (independent loads); thread g then adds
         // the NSL slices in order: a fixed summation order, one round of memory latency
         __shared__ float s_ps[8][64][2];
@@ -477,6 +532,9 @@ int cfgpp_op_softmax_rows(void* s, long rows, int ncols, void* stream) {
 // (src1 may be NULL / C1 = 0).  stats: device scratch of N * (1024*G*2 + G*2) floats (the two-launch form uses
 // the first N * 64 * G * 2 of them).
 void cfgpp_groupnorm_set_mode(int mode) { g_gn_mode = mode; }
+static int g_gn_prestats = 1;
+void cfgpp_groupnorm_set_prestats(int on) { g_gn_prestats = on ? 1 : 0; }
+int cfgpp_groupnorm_prestats_enabled() { return g_gn_prestats; }
 void cfgpp_layernorm_set_rows_per_wave(int rpw) { g_ln_rpw = (rpw == 1 || rpw == 2 || rpw == 4) ? rpw : 0; }
 
 int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
@@ -492,6 +550,7 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
     a.gamma = gamma; a.beta = beta;
     a.N = N; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.G = G; a.eps = eps; a.silu = silu;
     a.dst_padded = dst_padded; a.stats = stats; a.nblk = 0; a.gs = 1; a.pix_per_block = 0;
+    a.gst0 = nullptr; a.gst1 = nullptr; a.pre = 0;
     const int HW = H * W;
     const int cpg = C / G;
     // ---- (1) slab kernel: smallest gs (groups per workgroup) whose channel range is whole 16-B chunks ----
@@ -543,6 +602,35 @@ int cfgpp_op_groupnorm(const void* src0, const void* src1, void* dst, const floa
     while (apb > 16 && (long)N * cdiv(HW, apb) < 1024) apb >>= 1;
     b.pix_per_block = apb;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(HW, apb), N), dim3(256), 0, s, b);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// The same GroupNorm with the statistics taken from the producers of src0 / src1 (gst0 / gst1: [N * H * W / 32][C0 or C1][2] fp32,
+// IGemmArgs::gstat): a tiny finalize launch (N x G workgroups) + the apply launch - one read and one write of the tensor at full
+// parallelism at every feature-map size, instead of the statistics pass (64x64 level and up) or the one-workgroup-per-slab kernel
+// (32x32 and below).  stats: >= N * G * 2 floats.
+int cfgpp_op_groupnorm_pre(const void* src0, const void* src1, void* dst, const float* gamma, const float* beta,
+                           const float* gst0, const float* gst1, float* stats, int N, int H, int W, int C0, int C1, int G,
+                           float eps, int silu, int dst_padded, void* stream) {
+    const int C = C0 + C1;
+    CFGPP_REQUIRE(G > 0 && G <= 64 && C % G == 0, "groupnorm_pre: C=%d not divisible by G=%d (G<=64)", C, G);
+    CFGPP_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0, "groupnorm_pre: C0=%d C1=%d must be multiples of 8", C0, C1);
+    CFGPP_REQUIRE((H * W) % 32 == 0, "groupnorm_pre: H*W=%d must be a multiple of 32 (the producers' statistics blocks)", H * W);
+    CFGPP_REQUIRE(src0 && dst && gamma && beta && stats && gst0 && (C1 == 0 || (src1 && gst1)), "groupnorm_pre: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    GNArgs a;
+    a.src0 = (const half_t*)src0; a.src1 = (const half_t*)src1; a.dst = (half_t*)dst;
+    a.gamma = gamma; a.beta = beta;
+    a.N = N; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.G = G; a.eps = eps; a.silu = silu;
+    a.dst_padded = dst_padded; a.stats = stats; a.nblk = 0; a.gs = 1;
+    a.gst0 = gst0; a.gst1 = gst1; a.pre = 1;
+    const int HW = H * W;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, s, a);
+    int apb = 64;
+    while (apb > 16 && (long)N * cdiv(HW, apb) < 1024) apb >>= 1;
+    a.pix_per_block = apb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(HW, apb), N), dim3(256), 0, s, a);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -576,6 +576,13 @@ double cfgpp_unet_flops(cfgpp_unet* u, int rows) {
 double cfgpp_unet_device_bytes(cfgpp_unet* u) { return u ? u->dev_bytes : 0.0; }
 
 // ---- single-op wrappers for tests ----------------------------------------------
+// test hook: the next cfgpp_op_igemm launches write GroupNorm statistics of their output (IGemmArgs::gstat) into `buf`
+// ([M / 32][N][2] floats; null = off); cfgpp_op_igemm_gstat_written() = what the last launch reported through stat_flag
+static float* g_op_gstat = nullptr;
+static int g_op_gstat_flag = 0;
+void cfgpp_op_igemm_set_gstat(void* buf) { g_op_gstat = (float*)buf; }
+int cfgpp_op_igemm_gstat_written() { return g_op_gstat_flag; }
+
 int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int amode, int H, int W,
                    const void* w, int M, int N, const float* bias, const float* temb, int temb_ld,
                    const void* resid, int rmode, int rld, void* out, int omode, int old_, int epi, void* stream) {
@@ -584,6 +591,7 @@ int cfgpp_op_igemm(const void* a0, const void* a1, int C0, int C1, int taps, int
     a.w = (const half_t*)w; a.M = M; a.N = N; a.K = taps * (C0 + C1); a.bias = bias; a.temb = temb; a.temb_ld = temb_ld;
     a.rows_per_batch = H * W; a.resid = (const half_t*)resid; a.rmode = rmode; a.rld = rld;
     a.out = (half_t*)out; a.omode = omode; a.old = old_; a.epi = epi;
+    a.gstat = g_op_gstat; a.stat_flag = &g_op_gstat_flag; g_op_gstat_flag = 0;
     return igemm_launch(a, (hipStream_t)stream);
 }
 

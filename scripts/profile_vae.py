@@ -4,6 +4,7 @@ import os, sys, collections, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from cfgpp_amd.vae import HipVAE
 from cfgpp_amd import _lib
+if os.environ.get("CFGPP_GN_PRESTATS"): _lib.load().cfgpp_groupnorm_set_prestats(int(os.environ["CFGPP_GN_PRESTATS"]))
 if os.environ.get("TUNE_MASK"): _lib.load().cfgpp_igemm_set_tune_mask(int(os.environ["TUNE_MASK"], 0))      # e.g. 0xffffffff: also offer the big4 tiles
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 hw = int(sys.argv[2]) if len(sys.argv) > 2 else 64

@@ -1,7 +1,8 @@
 """Same-box, same-process A/B of whole UNet forwards:
     python scripts/r05_runs/ab_forward.py sd15 8 "base:mask=0xffff7fff;lin32:mask=0xffffffff;lin32_nomf16lin:mask=0xffffffff,mf16lin=0"
 variant = name:key=value,...  keys: mask (tuner candidate mask, bit c = tile config c), mf16lin (16x16x32 rule takes linears),
-rounds (that rule also takes grids of 2 .. n full rounds), mf16 (0 = rule off, 3 / 4 = stages).
+rounds (that rule also takes grids of 2 .. n full rounds), mf16 (0 = rule off, 3 / 4 = stages), prestats (GroupNorm takes the
+producers' statistics: 1 / 0).
 The synthetic state dict is generated once; every variant builds its own engine from it, tunes, and is timed as back-to-back
 predict() calls (3 x 20 forwards: min and median) - the number the sampling loop sees - plus the per-family sums and the pinned
 tile histogram of a profiled forward; `--table` prints the per-launch table of the LAST variant."""
@@ -47,6 +48,7 @@ for vn, kv in variants:
     lib.cfgpp_igemm_set_mf16_linear(int(kv.get("mf16lin", "1")))
     lib.cfgpp_igemm_set_mf16_rounds(int(kv.get("rounds", "2")))
     lib.cfgpp_igemm_set_mf16(int(kv.get("mf16", "4")))
+    lib.cfgpp_groupnorm_set_prestats(int(kv.get("prestats", "1")))
     t0 = time.time()
     eng = HipEngine(cfg, max_batch=B, weights=sd)
     eng.set_context(uc, c, te, ti)

@@ -288,6 +288,97 @@ def t_gn():
     return out
 
 
+@case("groupnorm_prestats")
+def t_gn_pre():
+    """GroupNorm fed by the statistics its producers' epilogues wrote (IGemmArgs::gstat): conv3x3 (+ bias + time embedding + residual)
+    through every tile family, then cfgpp_op_groupnorm_pre against torch's GroupNorm of the fp16 conv output; the per-(32-row block,
+    column) pairs must be bit-identical across tile configs; a concat of two producers with different widths (groups straddle the
+    sources); a producer with |mean| = 100 sigma (the cancellation case: rel-L2 must stay at fp16 output rounding); K-split launches
+    must report that they wrote nothing."""
+    out = {}
+    lib = H.lib()
+    lib.cfgpp_igemm_set_tail_split(0)
+    try:
+        # ---- one producer, many tile configs ----
+        N, Cin, Cout, Hh, Ww = 4, 128, 320, 32, 32
+        x = rnd(N, Cin, Hh, Ww, seed=90)
+        w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=91)
+        b = rnd(Cout, scale=0.1, seed=92) + 0.7
+        temb = rnd(N, Cout, scale=0.5, seed=93)
+        res = rnd(N, Cout, Hh, Ww, seed=94)
+        g, be = 1 + rnd(Cout, scale=0.1, seed=95), rnd(Cout, scale=0.1, seed=96)
+        xp, wp, rp = H.to_pn(x), H.pack_conv3(w), H.to_pn(res)
+        gst = torch.zeros((N * Hh * Ww // 32, Cout, 2), dtype=torch.float32, device=H.DEV)
+        base_gst = None
+        for c in (1, 3, 4, 5, 6, 7, 8, 12, 13, 14, 15, 16, 17, 19, 20, 24, 25, 26, 27):
+            lib.cfgpp_igemm_force_config(c)
+            gst.fill_(float("nan"))
+            lib.cfgpp_op_igemm_set_gstat(H.P(gst))
+            y = H.conv3x3(xp, wp, b.to(H.DEV), Hh, Ww, 1, temb.to(H.DEV), Cout, rp)
+            wrote = int(lib.cfgpp_op_igemm_gstat_written())
+            lib.cfgpp_op_igemm_set_gstat(None)
+            yf = H.from_pn(y).float().cpu()
+            ref = F.silu(F.group_norm(yf, 32, g, be, 1e-5))
+            got = H.groupnorm_pre(y, None, gst, None, g.to(H.DEV), be.to(H.DEV), 32, 1e-5, 1)
+            if base_gst is None:
+                base_gst = gst.clone()
+            # the pairs against their definition: per 32-row block and column, mean and sum of squared deviations of the fp16 outputs
+            blocks = yf.permute(0, 2, 3, 1).reshape(-1, 32, Cout).double()
+            mean_ref, m2_ref = blocks.mean(1), ((blocks - blocks.mean(1, keepdim=True)) ** 2).sum(1)
+            gc = gst.cpu().double()
+            out[f"conv_cfg{c}"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got), wrote=wrote,
+                                       same_pairs_as_cfg1=bool(torch.equal(gst, base_gst)),
+                                       mean_err=float((gc[..., 0] - mean_ref).abs().max()), m2_rel=float(((gc[..., 1] - m2_ref).abs() / (m2_ref + 1e-6)).max()))
+        lib.cfgpp_igemm_force_config(0)
+        # ---- concat of two producers (1 x 1 convs, 64 + 192 channels: groups of 8 straddle nothing, groups of (64+192)/32 = 8 ... and
+        #      320 + 640 -> 30-channel groups that DO straddle the boundary) ----
+        for name, Ca, Cb, Hh2 in (("cat_64_192", 64, 192, 16), ("cat_640_320", 640, 320, 16)):
+            xa, xb = rnd(2, 64, Hh2, Hh2, seed=100), rnd(2, 128, Hh2, Hh2, seed=101)
+            wa, wb_ = rnd(Ca, 64, scale=1 / 8, seed=102), rnd(Cb, 128, scale=128 ** -0.5, seed=103)
+            ba, bb = rnd(Ca, scale=0.3, seed=104), rnd(Cb, scale=0.3, seed=105) - 1.0
+            ga, gb_ = torch.zeros((2 * Hh2 * Hh2 // 32, Ca, 2), device=H.DEV), torch.zeros((2 * Hh2 * Hh2 // 32, Cb, 2), device=H.DEV)
+            lib.cfgpp_op_igemm_set_gstat(H.P(ga))
+            ya = H.conv1x1_2src(H.to_pn(xa), None, wa.to(H.DEV, torch.float16), ba.to(H.DEV))
+            wrote_a = int(lib.cfgpp_op_igemm_gstat_written())
+            lib.cfgpp_op_igemm_set_gstat(H.P(gb_))
+            yb = H.conv1x1_2src(H.to_pn(xb), None, wb_.to(H.DEV, torch.float16), bb.to(H.DEV))
+            wrote_b = int(lib.cfgpp_op_igemm_gstat_written())
+            lib.cfgpp_op_igemm_set_gstat(None)
+            C = Ca + Cb
+            gg, bg = 1 + rnd(C, scale=0.1, seed=106), rnd(C, scale=0.1, seed=107)
+            ref = F.group_norm(torch.cat([H.from_pn(ya).float().cpu(), H.from_pn(yb).float().cpu()], 1), 32, gg, bg, 1e-6)
+            got = H.groupnorm_pre(ya, yb, ga, gb_, gg.to(H.DEV), bg.to(H.DEV), 32, 1e-6, 0)
+            old = H.groupnorm(ya, yb, gg.to(H.DEV), bg.to(H.DEV), 32, 1e-6, 0)
+            out[name] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=H.halo_is_zero(got), wrote=wrote_a * wrote_b,
+                             vs_own_pass=float((H.from_pn(got).float() - H.from_pn(old).float()).abs().max()))
+        # ---- |mean| = 100 sigma: bias 50, outputs with sigma ~0.5 ----
+        xs = rnd(2, 64, 16, 16, seed=110)
+        ws = rnd(64, 64, scale=0.5 / 8, seed=111)
+        bs = torch.full((64,), 50.0)
+        gl = torch.zeros((2 * 256 // 32, 64, 2), device=H.DEV)
+        lib.cfgpp_op_igemm_set_gstat(H.P(gl))
+        yl = H.conv1x1_2src(H.to_pn(xs), None, ws.to(H.DEV, torch.float16), bs.to(H.DEV))
+        lib.cfgpp_op_igemm_set_gstat(None)
+        g1, b1 = torch.ones(64), torch.zeros(64)
+        ref = F.group_norm(H.from_pn(yl).double().cpu(), 32, g1.double(), b1.double(), 1e-5).float()
+        got = H.groupnorm_pre(yl, None, gl, None, g1.to(H.DEV), b1.to(H.DEV), 32, 1e-5, 0)
+        out["large_mean"] = dict(H.err_stats(H.from_pn(got), ref), halo_zero=True, wrote=1)
+        # ---- a K-split launch reports that it wrote nothing ----
+        lib.cfgpp_igemm_set_tail_split(1)
+        xk = rnd(2, 1280, 8, 8, seed=120)
+        wk = rnd(1280, 1280, 3, 3, scale=(9 * 1280) ** -0.5, seed=121)
+        gk = torch.zeros((2 * 64 // 32, 1280, 2), device=H.DEV)
+        lib.cfgpp_op_igemm_set_gstat(H.P(gk))
+        H.conv3x3(H.to_pn(xk), H.pack_conv3(wk), None, 8, 8, 1)
+        out["ksplit_reports_no_stats"] = dict(rel_l2=0.0, max_abs=0.0, finite=True, halo_zero=True, wrote=1 - int(lib.cfgpp_op_igemm_gstat_written()))
+        lib.cfgpp_op_igemm_set_gstat(None)
+    finally:
+        lib.cfgpp_op_igemm_set_gstat(None)
+        lib.cfgpp_igemm_force_config(0)
+        lib.cfgpp_igemm_set_tail_split(1)
+    return out
+
+
 @case("layernorm")
 def t_ln():
     out = {}

@@ -124,6 +124,18 @@ def groupnorm(x0_pn, x1_pn, gamma, beta, G, eps, silu, dst_padded=True):
     return dst
 
 
+def groupnorm_pre(x0_pn, x1_pn, gst0, gst1, gamma, beta, G, eps, silu, dst_padded=True):
+    """GroupNorm with the statistics its inputs' producers left behind (cfgpp_op_igemm_set_gstat)"""
+    N, Hp, Wp, C0 = x0_pn.shape
+    H, W = Hp - 2, Wp - 2
+    C1 = 0 if x1_pn is None else x1_pn.shape[3]
+    stats = torch.zeros(N * G * 2, dtype=torch.float32, device=DEV)
+    dst = empty_pn(N, H, W, C0 + C1) if dst_padded else torch.empty((N * H * W, C0 + C1), dtype=torch.float16, device=DEV)
+    check(lib().cfgpp_op_groupnorm_pre(P(x0_pn), P(x1_pn), P(dst), P(gamma), P(beta), P(gst0), P(gst1), P(stats), N, H, W, C0, C1, G,
+                                       float(eps), int(silu), int(dst_padded), stream()), "cfgpp_op_groupnorm_pre")
+    return dst
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     y = torch.empty_like(x)
     check(lib().cfgpp_op_layernorm(P(x), P(y), P(gamma), P(beta), x.shape[0], x.shape[1], float(eps), stream()),

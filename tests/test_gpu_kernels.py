@@ -86,6 +86,22 @@ def test_groupnorm_silu_concat(diag):
     assert all(v.get("halo_zero", True) for v in r.values())
 
 
+def test_groupnorm_from_producer_statistics(diag):
+    """round 5: the conv / projection epilogues leave per-(32-row block, column) {mean, M2} pairs of what they stored, GroupNorm
+    combines them (Chan) instead of re-reading the tensor: parity vs torch through every tile family, pairs bit-identical across
+    tile configs (results stay independent of tuning), concat of two producers, the |mean| = 100 sigma case at fp16 output rounding,
+    K-split launches report that they wrote nothing"""
+    r = _check(diag, diag.t_gn_pre, "groupnorm_prestats", rel=6e-4)
+    bad = {k: v for k, v in r.items() if not (v["wrote"] and v["halo_zero"])}
+    assert not bad, bad
+    for k, v in r.items():
+        if k.startswith("conv_cfg"):
+            assert v["same_pairs_as_cfg1"], k
+            assert v["mean_err"] < 2e-5 and v["m2_rel"] < 1e-3, (k, v)
+    assert r["large_mean"]["rel_l2"] < 2.5e-4, r["large_mean"]
+    assert all(r[k]["vs_own_pass"] <= 2e-3 for k in ("cat_64_192", "cat_640_320"))
+
+
 def test_layernorm(diag):
     _check(diag, diag.t_ln, "layernorm")
 
