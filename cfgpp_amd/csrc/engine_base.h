@@ -33,7 +33,7 @@ struct Tensor {   // halo-padded NHWC fp16 activation
     // GroupNorm statistics of this tensor as its PRODUCER left them (IGemmArgs::gstat: [rows * H * W / 32][C][2] fp32), pooled with
     // the activation buffer; *gst_ok (host, one per acquired tensor = per producer in the plan) is set by the producer's igemm_launch
     // on every forward: 1 = the buffer holds this forward's statistics, 0 = the producer could not write them (K-split launch,
-    // non-igemm producer: never set) and the consumer runs its own statistics pass.  Null on maps under 16 x 16 pixels.
+    // non-igemm producer: never set) and the consumer runs its own statistics pass.  Null on maps under 32 x 32 pixels.
     float* gst = nullptr;
     int* gst_ok = nullptr;
 };
@@ -166,7 +166,9 @@ struct EngineBase {
         t.gst_ok = &gst_flags.back();
         if (!fl.empty()) { t.p = fl.back().first; t.gst = fl.back().second; fl.pop_back(); return t; }
         t.p = (half_t*)dmalloc((size_t)max_rows * (H + 2) * (W + 2) * C * sizeof(half_t));
-        if (H * W >= 256 && (H * W) % 32 == 0 && C % 8 == 0)
+        // (32 x 32 maps and larger: below that the one-launch slab kernel beats finalize + apply - 16 x 16: 14.6 vs 18 us per GroupNorm,
+        //  profiles/r05/ab/forward_ab_gn_prestats_*)
+        if (H * W >= 1024 && (H * W) % 32 == 0 && C % 8 == 0)
             t.gst = (float*)dmalloc((size_t)max_rows * (H * W / 32) * C * 2 * sizeof(float), false);
         return t;
     }

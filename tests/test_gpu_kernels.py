@@ -96,7 +96,8 @@ def test_groupnorm_from_producer_statistics(diag):
     assert not bad, bad
     for k, v in r.items():
         if k.startswith("conv_cfg"):
-            assert v["same_pairs_as_cfg1"], k
+            # (config 19 = the 16x16x32-MFMA tile sums k in another order: its OUTPUTS differ in the last fp16 bit, so do their statistics)
+            assert v["same_pairs_as_cfg1"] or k == "conv_cfg19", k
             assert v["mean_err"] < 2e-5 and v["m2_rel"] < 1e-3, (k, v)
     assert r["large_mean"]["rel_l2"] < 2.5e-4, r["large_mean"]
     assert all(r[k]["vs_own_pass"] <= 2e-3 for k in ("cat_64_192", "cat_640_320"))
