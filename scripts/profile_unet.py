@@ -11,7 +11,8 @@ _lib.load().cfgpp_igemm_set_staging(staging)
 _lib.load().cfgpp_igemm_set_autotune(int(os.environ.get("AUTOTUNE", "1")))
 # A/B switches: TUNE_MASK=0x5f2 = the round-2 mid-round candidate set without the tile-walk stage; BIG_SPLIT=0 turns the
 # big-tile K-split rule off; LN_RPW = LayerNorm rows per wave
-_lib.load().cfgpp_igemm_set_tune_mask(int(os.environ.get("TUNE_MASK", "0xffffffff"), 0))
+if os.environ.get("TUNE_MASK"):      # default: the library's own candidate set (cfgpp_igemm_set_tune_mask)
+    _lib.load().cfgpp_igemm_set_tune_mask(int(os.environ["TUNE_MASK"], 0))
 _lib.load().cfgpp_igemm_set_big_split(int(os.environ.get("BIG_SPLIT", "0")))
 _lib.load().cfgpp_layernorm_set_rows_per_wave(int(os.environ.get("LN_RPW", "0")))
 _lib.load().cfgpp_igemm_set_mf16_heads(int(os.environ.get("MF16_HEADS", "1")))       # 1: head-major epilogue of that tile (unvalidated)
