@@ -326,6 +326,9 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
     (max over ranks) and return the JSON fields of that workload"""
     from cfgpp_amd import dist as D
     kind, name, cfg_name, nfe, lam, B, img, desc = WORKLOADS[config]
+    if batch and batch != B:
+        import re
+        desc = re.sub(r"batch=\d+/GPU", f"batch={batch}/GPU", desc)      # the line names the per-GPU batch that actually ran
     B = batch or B
     nfe = nfe_override or nfe
     log(f"building engine {cfg_name} max_batch={B}")
