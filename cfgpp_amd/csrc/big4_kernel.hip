@@ -48,8 +48,8 @@ big4_kernel(const IGemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
-    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    int tile_m, tile_n;
+    tile_of(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -117,6 +117,9 @@ void cfgpp_igemm_set_big_split(int min_kt);
 /* tile walk of the implicit GEMM: -1 (default) by operand bytes / the tuner's pin, 0 always M-major, 1 always N-major; the
  * result does not depend on it */
 void cfgpp_igemm_set_n_major(int mode);
+/* 1 (default): launches whose round-by-round byte count says so take the XCD-blocked 2-D tile walk (IGemmArgs::walk_bn,
+ * csrc/igemm_kernel.hip walk_plan); 0: the 1-D M- / N-major walks only (A/B).  Results do not depend on it. */
+void cfgpp_igemm_set_blocked_walk(int on);
 /* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 27; 24 - 26 = the one-wave-per-SIMD tiles of
  * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf1ffffff: everything but 25 / 26 / 27, which lose in situ
  * (profiles/r05/ab/) */

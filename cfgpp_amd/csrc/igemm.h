@@ -63,6 +63,12 @@ struct IGemmArgs {
     int n_major;              // 1: N-major tile walk (weight slabs stay L2-resident): weight-heavy launches
     int walk_div;             // tiles along the minor axis of the walk (filled by igemm_launch)
     int walk_hint;            // decoded from cfg_hint by igemm_launch
+    // XCD-blocked 2-D walk (round 5; 0 = off): the T tiles (T % 8 == 0) are cut into walk_bm x walk_bn = 8 rectangular blocks of
+    // walk_tmb x walk_tnb tiles, one per XCD (workgroup b runs on XCD b % 8 and the numbering hands an XCD a contiguous range of
+    // walk_per = T / 8 indices); inside a block the order is M- or N-major as n_major says.  The workgroups an XCD runs at the same
+    // time then share activation row-blocks AND weight slabs in its 4-MiB L2.  Chosen by the launcher from a count of the bytes
+    // each round of resident workgroups pulls into the L2 (walk_plan); results do not depend on it.
+    int walk_bn, walk_per, walk_tmb, walk_tnb;
     int split;                // >= 2: K-split every tile this many ways (igemm_launch's big-tile rule / diagnostics); 0: launcher's rule
     // ---- diagnostics (cfgpp_igemm_timeline): per-workgroup time stamps of ONE chosen launch, null otherwise ----
     int par_nb;               // time-embedding rows (batches) a tile stages in LDS (set by the launcher: covers every batch a tile's rows touch)

@@ -54,6 +54,24 @@ __device__ __forceinline__ int padded_pix(int m, int HW, int W, int H) {
 }
 
 
+// workgroup index (XCD-contiguous numbering) -> tile.  Everything here is wave-uniform: the quotients go back to SGPRs
+// (readfirstlane), so the blocked form costs no vector registers beyond the prologue.
+__device__ __forceinline__ int qdiv_u(int a, int d) { return __builtin_amdgcn_readfirstlane(qdiv(a, d)); }
+__device__ __forceinline__ void tile_of(const IGemmArgs& p, int wg, int& tile_m, int& tile_n) {
+    if (p.walk_bn > 0) {                                   // XCD-blocked 2-D walk (IGemmArgs::walk_bn)
+        const int x = qdiv_u(wg, p.walk_per), i = wg - x * p.walk_per;
+        const int bmi = qdiv_u(x, p.walk_bn), bni = x - bmi * p.walk_bn;
+        int im, in;
+        if (p.n_major) { in = qdiv_u(i, p.walk_tmb); im = i - in * p.walk_tmb; }
+        else { im = qdiv_u(i, p.walk_tnb); in = i - im * p.walk_tnb; }
+        tile_m = bmi * p.walk_tmb + im; tile_n = bni * p.walk_tnb + in;
+    } else {
+        // (one division by a launcher-provided divisor: walk_div = ntn (M-major) or ntm (N-major))
+        const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
+        tile_m = p.n_major ? wr : wq; tile_n = p.n_major ? wq : wr;
+    }
+}
+
 // ---- epilogue parameters in LDS -----------------------------------------------------------------------------------------
 // The per-column parameters of an epilogue (bias, per-batch time embedding, LayerNorm column sums) used to be read from
 // global memory where they are consumed: one 16-byte load per 4 columns, each inside its own `if (p.bias)` block and therefore

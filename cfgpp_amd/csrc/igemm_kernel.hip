@@ -81,8 +81,8 @@ igemm_kernel(const IGemmArgs p) {
     // launches (GEGLU at M = 4096: 26 MB of weights vs 10 MB of activations; PMC showed 56 % L2 misses M-major).
     // The launcher picks by operand bytes (IGemmArgs::n_major); the result does not depend on it.
     // (one division by a launcher-provided divisor: a two-sided branch here cost the 256 x 320 kernel 30 VGPRs -> spills)
-    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;          // walk_div = ntn (M-major) or ntm (N-major)
-    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    int tile_m, tile_n;
+    tile_of(p, wg, tile_m, tile_n);                        // (K-split tails never take the blocked walk: walk_bn = 0)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -553,8 +553,8 @@ tile32_kernel(const IGemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
-    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    int tile_m, tile_n;
+    tile_of(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -957,8 +957,8 @@ igemm16_kernel(const IGemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int wq = qdiv(wg, p.walk_div), wr = wg - wq * p.walk_div;
-    const int tile_m = p.n_major ? wr : wq, tile_n = p.n_major ? wq : wr;
+    int tile_m, tile_n;
+    tile_of(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1198,6 +1198,61 @@ static int par_slots(const IGemmArgs& a, int BM) {
     return span < nbatch ? span : nbatch;
 }
 
+// ---- XCD-blocked 2-D tile walk (IGemmArgs::walk_bn) ----------------------------------------------------------------------
+// An XCD (32 CUs, one 4-MiB L2) runs its share of the tiles in ROUNDS of the workgroups resident at a time, and what a round pulls
+// through the fabric is the set of distinct activation row-blocks and weight slabs its tiles touch.  With a 1-D walk a round of 32
+// tiles is a strip - e.g. the SDXL GEGLU (16 x 32 tiles of 256 x 320), N-major: every round touches ALL 16 activation row-blocks
+// (10.5 MB, more than the L2 holds) beside 2 weight slabs, so the activation matrix crosses the fabric twice per XCD; the PMC
+// passes folded onto launch classes (profiles/r05/pmc_per_launch_class_*.txt) show exactly that count, 3.0x the algorithmic bytes.
+// A rectangular block per XCD makes the rounds rectangles too.  walk_plan() counts the bytes per XCD for the walk the launch would
+// take and for the 2 x 4 / 4 x 2 block forms (either inner order) and switches when a block form saves >= 15 %.  Results do not
+// depend on the walk; the tuner's pinned 1-D walks are left alone.
+static int g_walk_blocked = 1;
+extern "C" void cfgpp_igemm_set_blocked_walk(int on) { g_walk_blocked = on ? 1 : 0; }
+static void walk_plan(IGemmArgs& a, int BM, int BN, int ntm, int ntn, int smem) {
+    a.walk_bn = 0; a.walk_per = 0; a.walk_tmb = 0; a.walk_tnb = 0;
+    const int T = ntm * ntn;
+    if (!g_walk_blocked || a.walk_hint || (T & 7) || T < 64 || a.ksplit > 1 || a.n_main != T) return;
+    const int per = T >> 3;
+    int wpc = smem > 0 ? (160 * 1024) / smem : 1;
+    wpc = wpc < 1 ? 1 : wpc > 4 ? 4 : wpc;
+    const int R = 32 * wpc;                                   // tiles an XCD runs at a time
+    const double a_row = 2.0 * BM * (a.C0 + a.C1) * (a.amode == 2 ? 4.0 : a.amode == 3 ? 0.25 : 1.0);
+    const double w_col = 2.0 * BN * a.K;
+    // bytes XCD 0 pulls in, round by round: distinct tile rows x a_row + distinct tile columns x w_col
+    auto cost = [&](auto tile_at) {
+        double tot = 0.0;
+        for (int r0 = 0; r0 < per; r0 += R) {
+            unsigned long long seen_m[8] = {0}, seen_n[8] = {0};      // bitsets: ntm, ntn <= 512
+            int nm = 0, nn = 0;
+            for (int i = r0; i < per && i < r0 + R; ++i) {
+                int tm, tn; tile_at(i, tm, tn);
+                if (tm < 512 && !((seen_m[tm >> 6] >> (tm & 63)) & 1ull)) { seen_m[tm >> 6] |= 1ull << (tm & 63); ++nm; }
+                if (tn < 512 && !((seen_n[tn >> 6] >> (tn & 63)) & 1ull)) { seen_n[tn >> 6] |= 1ull << (tn & 63); ++nn; }
+            }
+            tot += nm * a_row + nn * w_col;
+        }
+        return tot;
+    };
+    if (ntm > 512 || ntn > 512) return;
+    const int div1 = a.n_major ? ntm : ntn;
+    const double now = cost([&](int i, int& tm, int& tn) { const int q = i / div1, r = i - q * div1; tm = a.n_major ? r : q; tn = a.n_major ? q : r; });
+    double best = now; int best_bn = 0, best_inner = 0, best_tmb = 0, best_tnb = 0;
+    for (int bn : {4, 2}) {
+        const int bm = 8 / bn;
+        if (ntm % bm || ntn % bn) continue;
+        const int tmb = ntm / bm, tnb = ntn / bn;
+        for (int inner = 0; inner < 2; ++inner) {             // 0: M-major inside the block, 1: N-major
+            const double c = cost([&](int i, int& tm, int& tn) {
+                if (inner) { tn = i / tmb; tm = i - tn * tmb; } else { tm = i / tnb; tn = i - tm * tnb; } });
+            if (c < best) { best = c; best_bn = bn; best_inner = inner; best_tmb = tmb; best_tnb = tnb; }
+        }
+    }
+    if (best_bn && best <= 0.85 * now) {
+        a.walk_bn = best_bn; a.walk_per = per; a.walk_tmb = best_tmb; a.walk_tnb = best_tnb; a.n_major = best_inner;
+    }
+}
+
 // GroupNorm statistics of the output (IGemmArgs::gstat): only the LDS-staged plain-store epilogues of whole-K tiles write them.
 // Decided HERE, per launch, and reported to the caller through *stat_flag (host memory): a consumer must not trust a buffer the
 // launch did not fill.
@@ -1261,6 +1316,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     stats_decide(a, WM * WN * 32 * (WTN * 2 + 16) <= NST * (BM + BN) * 128 && a.staged_epi && n_tail == 0);
     if (n_tail > 0) a.n_major = 0;                     // K-split tiles keep the M-major numbering the reduce kernel uses
     a.walk_div = a.n_major ? cdiv(a.M, BM) : cdiv(a.N, BN);
+    walk_plan(a, BM, BN, cdiv(a.M, BM), cdiv(a.N, BN), smem);
     a.tl = tl_take(WM * 100 + WN * 10 + (GLDS ? 1 : 0), a.n_main + n_tail * a.ksplit, NTHR, BM, BN, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main + n_tail * a.ksplit), dim3(NTHR), smem, stream, a);
     if (n_tail > 0)
@@ -1309,6 +1365,7 @@ int launch_tile32_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    walk_plan(a, BM, BN, ntm, ntn, smem);
     stats_decide(a, NTHR / 64 * 32 * (WTN * 2 + 16) <= NST * (BM + BN) * 64 && a.staged_epi);
     a.tl = tl_take(3200 + WM * 100 + WN * 10, a.n_main, NTHR, BM, BN, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(NTHR), smem, stream, a);
@@ -1358,6 +1415,7 @@ int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    walk_plan(a, 128, 160, ntm, ntn, smem);
     stats_decide(a, true);
     a.tl = tl_take(16, a.n_main, 512, 128, 160, NST, a);
     hipLaunchKernelGGL(kern, dim3(a.n_main), dim3(512), smem, stream, a);
@@ -1393,6 +1451,7 @@ static int launch_big4(int cfg, const IGemmArgs& a_in, hipStream_t stream) {
     a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
     if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
     a.walk_div = a.n_major ? ntm : ntn;
+    walk_plan(a, BM, BN, ntm, ntn, smem);
     stats_decide(a, true);
     a.tl = tl_take(4000 + cfg, a.n_main, 256, BM, BN, 2, a);
     return big4_run(cfg, a, a.n_main, smem, stream);

@@ -49,6 +49,7 @@ for vn, kv in variants:
     lib.cfgpp_igemm_set_mf16_rounds(int(kv.get("rounds", "2")))
     lib.cfgpp_igemm_set_mf16(int(kv.get("mf16", "4")))
     lib.cfgpp_groupnorm_set_prestats(int(kv.get("prestats", "1")))
+    lib.cfgpp_igemm_set_blocked_walk(int(kv.get("blocked", "1")))
     t0 = time.time()
     eng = HipEngine(cfg, max_batch=B, weights=sd)
     eng.set_context(uc, c, te, ti)

@@ -97,3 +97,33 @@ def test_packed_gelu_polynomial_constants():
     assert err.max() < 1e-5, (err.max(), x[err.argmax()])
     assert np.abs(y[x <= -c]).max() < 2e-6 and np.abs(y[x >= c] - x[x >= c]).max() < 2e-5
     assert y[np.abs(x) < 1e-5].max() < 1e-5
+
+
+def test_xcd_blocked_tile_walk_is_a_permutation_and_blocks_are_rectangles():
+    """IGemmArgs::walk_bn (csrc/igemm_device.h tile_of, restated): the XCD-contiguous workgroup index -> (tile_m, tile_n) map of the
+    blocked 2-D walk visits every tile exactly once, and the walk_per consecutive indices an XCD owns form one walk_tmb x walk_tnb
+    rectangle - for every block shape and inner order the launcher can choose (igemm_kernel.hip walk_plan)"""
+    def tile_of(wg, per, bn, tmb, tnb, n_major):
+        x, i = divmod(wg, per)
+        bmi, bni = divmod(x, bn)
+        if n_major:
+            tn, tm = divmod(i, tmb)
+        else:
+            tm, tn = divmod(i, tnb)
+        return bmi * tmb + tm, bni * tnb + tn
+
+    for ntm, ntn in ((16, 32), (32, 8), (16, 16), (64, 4), (8, 40), (256, 2)):
+        T = ntm * ntn
+        for bn in (4, 2):
+            bm = 8 // bn
+            if ntm % bm or ntn % bn:
+                continue
+            tmb, tnb, per = ntm // bm, ntn // bn, T // 8
+            assert tmb * tnb == per
+            for n_major in (0, 1):
+                tiles = [tile_of(w, per, bn, tmb, tnb, n_major) for w in range(T)]
+                assert sorted(tiles) == [(m, n) for m in range(ntm) for n in range(ntn)], (ntm, ntn, bn, n_major)
+                for x in range(8):
+                    blk = tiles[x * per:(x + 1) * per]
+                    ms, ns = {m for m, _ in blk}, {n for _, n in blk}
+                    assert len(ms) == tmb and len(ns) == tnb and max(ms) - min(ms) == tmb - 1 and max(ns) - min(ns) == tnb - 1
