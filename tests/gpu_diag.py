@@ -768,7 +768,8 @@ def main():
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     print("[diag] device:", torch.cuda.get_device_name(0), flush=True)
-    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_big(); t_tail(); t_gn(); t_ln(); t_attn(); t_heads()
+    t_gemm_t(); t_gemm(); t_geglu(); t_conv(); t_conv_s2(); t_conv_up(); t_conv1(); t_big(); t_tail(); t_gn(); t_gn_pre(); t_ln(); t_attn(); t_heads()
+    t_tile32(); t_big4()
     t_cio(); t_small(); t_step()
     t_unet_tiny_sd(); t_unet_tiny_xl()
     if not args.quick:
