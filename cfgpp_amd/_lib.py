@@ -106,6 +106,7 @@ DEBUG_PROTOTYPES = {
     "cfgpp_igemm_set_tail_split": (None, [_I]),
     "cfgpp_igemm_set_autotune": (None, [_I]),
     "cfgpp_igemm_set_blocked_walk": (None, [_I]),
+    "cfgpp_igemm_walk_plan_probe": (None, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int)]),
     "cfgpp_igemm_set_n_major": (None, [_I]),
     "cfgpp_igemm_force_split": (None, [_I]),
     "cfgpp_igemm_set_split_tile": (None, [_I]),

@@ -120,6 +120,9 @@ void cfgpp_igemm_set_n_major(int mode);
 /* 1 (default): launches whose round-by-round byte count says so take the XCD-blocked 2-D tile walk (IGemmArgs::walk_bn,
  * csrc/igemm_kernel.hip walk_plan); 0: the 1-D M- / N-major walks only (A/B).  Results do not depend on it. */
 void cfgpp_igemm_set_blocked_walk(int on);
+/* host-only probe of that choice (tests; no GPU): token GEMM M x N x K on BM x BN tiles, smem bytes of LDS per workgroup, the 1-D
+ * default (n_major); out5 = {blocks along M (0: the 1-D walk stays), along N, tiles per block along M, along N, inner order} */
+void cfgpp_igemm_walk_plan_probe(int M, int N, int K, int BM, int BN, int smem, int n_major, int* out5);
 /* in-situ tuning candidates: bit c set = tile config c may be pinned (c = 1 .. 27; 24 - 26 = the one-wave-per-SIMD tiles of
  * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf1ffffff: everything but 25 / 26 / 27, which lose in situ
  * (profiles/r05/ab/) */

@@ -22,6 +22,7 @@
 //     one XCD's L2.
 // Epilogues: bias, per-batch time-embedding add, residual add, GEGLU, and the
 // head-major Q / K / V^T scatter the attention kernel consumes.
+#include <cstring>
 #include <map>
 #include <tuple>
 #include <type_traits>
@@ -1251,6 +1252,18 @@ static void walk_plan(IGemmArgs& a, int BM, int BN, int ntm, int ntn, int smem) 
     if (best_bn && best <= 0.85 * now) {
         a.walk_bn = best_bn; a.walk_per = per; a.walk_tmb = best_tmb; a.walk_tnb = best_tnb; a.n_major = best_inner;
     }
+}
+
+// host-only probe of walk_plan for tests (no GPU involved): token GEMM M x N x K on BM x BN tiles with `smem` bytes of LDS per
+// workgroup and the given 1-D default; out5 = {walk_bm (0 = the 1-D walk stays), walk_bn, tiles per block along M, along N, inner
+// order (1 = N-major)}
+extern "C" void cfgpp_igemm_walk_plan_probe(int M, int N, int K, int BM, int BN, int smem, int n_major, int* out5) {
+    IGemmArgs a; std::memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K; a.C0 = K; a.amode = 0; a.ksplit = 1; a.n_major = n_major;
+    const int ntm = cdiv(M, BM), ntn = cdiv(N, BN);
+    a.n_main = ntm * ntn;
+    walk_plan(a, BM, BN, ntm, ntn, smem);
+    out5[0] = a.walk_bn ? 8 / a.walk_bn : 0; out5[1] = a.walk_bn; out5[2] = a.walk_tmb; out5[3] = a.walk_tnb; out5[4] = a.n_major;
 }
 
 // GroupNorm statistics of the output (IGemmArgs::gstat): only the LDS-staged plain-store epilogues of whole-K tiles write them.

@@ -127,3 +127,23 @@ def test_xcd_blocked_tile_walk_is_a_permutation_and_blocks_are_rectangles():
                     blk = tiles[x * per:(x + 1) * per]
                     ms, ns = {m for m, _ in blk}, {n for _, n in blk}
                     assert len(ms) == tmb and len(ns) == tnb and max(ms) - min(ms) == tmb - 1 and max(ns) - min(ns) == tnb - 1
+
+
+def test_walk_plan_takes_the_blocked_walk_where_the_round_count_says_so():
+    """the launcher's choice (igemm_kernel.hip walk_plan, probed on the host - no GPU): the SDXL GEGLU (M = 4096, N = 10240, K = 1280
+    on 256 x 320 tiles, one workgroup per CU, N-major by default) goes to 2 x 4 blocks of 8 x 8 tiles, N-major inside - the form
+    whose count, 8 x 2 x (8 x 655 KB + 4 x 819 KB) + 42 MB of writes = 178 MB, the PMC fold measured as 178.8 MB per launch
+    (profiles/r05/pmc_per_launch_class_sdxl_rows4_blocked_walk.txt); the 128 x 160 grids of the M = 4096 x N = 1280 class
+    (32 x 8 tiles: block forms save 7 %) and grids that are not a multiple of 8 tiles keep their 1-D walk"""
+    import ctypes as C
+    from cfgpp_amd import _lib
+    lib = _lib.load()
+    out = (C.c_int * 5)()
+    lib.cfgpp_igemm_walk_plan_probe(4096, 10240, 1280, 256, 320, 155136, 1, out)
+    assert list(out) == [2, 4, 8, 8, 1], list(out)
+    lib.cfgpp_igemm_walk_plan_probe(4096, 1280, 5120, 128, 160, 150000, 0, out)      # FF-out on the 16x16x32 tile
+    assert out[0] == 0 and out[1] == 0, list(out)
+    lib.cfgpp_igemm_walk_plan_probe(4096, 3840, 1280, 256, 256, 140000, 0, out)      # QKV: 16 x 15 tiles, no block form divides it
+    assert out[0] == 0, list(out)
+    lib.cfgpp_igemm_walk_plan_probe(1000, 960, 320, 256, 320, 155136, 0, out)        # 4 x 3 = 12 tiles: not a multiple of 8
+    assert out[0] == 0, list(out)
