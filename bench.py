@@ -384,7 +384,7 @@ def run_workload(args, config, rank, world, dev, steps, warmup, batch=0, nfe_ove
         "config": {"workload": desc, "per_gpu_batch": B, "global_batch": total, "nfe": nfe, "lambda": lam,
                    "unet_batch_rows": rows, "includes": ("VAE encode (HIP kernels), " if "inversion" in name else "") +
                    "set_context (cross-attention K/V of every block; once per job), UNet + fused CFG++ step x NFE, VAE decode (HIP kernels), D2H copy",
-                   "weights": "seeded synthetic, exact diffusers shapes", "flops_per_image": flops_per_image,
+                   "weights": "seeded synthetic, exact diffusers shapes", "build_id": _build_id(), "flops_per_image": flops_per_image,
                    "whole_path_frac_of_mfma_peak": round(value * flops_per_image / (world * PEAK_MFMA_FP16), 4)},
         "ranks": {"job_ms_min": round(min(flat) * 1e3, 2), "job_ms_max": round(max(flat) * 1e3, 2),
                   "job_ms_mean_per_rank": [round(sum(r) / len(r) * 1e3, 2) for r in per_rank],
@@ -438,6 +438,11 @@ def self_launch(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this host driver
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def _build_id():
+    from cfgpp_amd import _lib
+    return _lib.build_id()
 
 
 def main():

@@ -40,6 +40,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_long
 # name -> (restype, argtypes); every symbol include/cfgpp.h declares (the drop-in boundary)
 PROTOTYPES = {
     "cfgpp_last_error": (C.c_char_p, []),
+    "cfgpp_build_id": (C.c_char_p, []),
     "cfgpp_step_ddim": (_I, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
     "cfgpp_step_ddim_h": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _F, _I, _I, _L, _P]),
     "cfgpp_kdiff_input": (_I, [_P, _P, _F, _I, _L, _P]),
@@ -53,6 +54,7 @@ PROTOTYPES = {
     "cfgpp_unet_finalize": (_I, [_P]),
     "cfgpp_unet_set_context": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "cfgpp_unet_forward": (_I, [_P, _P, _I, _I, _F, _P, _I, _P]),
+    "cfgpp_sample_graph_ddim": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _I, C.POINTER(C.c_float), _I, _F, _I, _I, _P]),
     "cfgpp_unet_profile": (_I, [_P, _P, _I, _I, _F, _P, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_char_p, _L]),
     "cfgpp_unet_tuning": (_I, [_P, _I, C.POINTER(C.c_int), _I, _I]),
     "cfgpp_unet_flops": (C.c_double, [_P, _I]),
@@ -116,6 +118,7 @@ DEBUG_PROTOTYPES = {
     "cfgpp_igemm_set_mf16_linear": (None, [_I]),
     "cfgpp_igemm_set_big_split": (None, [_I]),
     "cfgpp_igemm_set_tune_mask": (None, [C.c_uint]),
+    "cfgpp_igemm_tuner_state": (C.c_uint, []),
     "cfgpp_igemm_timeline": (None, [_P, _L, _I]),
     "cfgpp_igemm_timeline_info": (None, [C.POINTER(C.c_int)]),
     "cfgpp_groupnorm_set_mode": (None, [_I]),
@@ -155,6 +158,11 @@ def load():
         lib.cfgpp_igemm_set_autotune(0)
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """provenance string of the loaded binary (include/cfgpp.h: cfgpp_build_id)"""
+    return load().cfgpp_build_id().decode("utf-8", "replace")
 
 
 def last_error() -> str:

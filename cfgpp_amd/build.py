@@ -3,6 +3,7 @@ extension machinery: plain ``hipcc -c`` per source + one link, so the ``.so``
 travels with the repo snapshot to the GPU box."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -61,27 +62,78 @@ def _deps(src: str) -> set:
     return seen
 
 
-def _newer(src: str, dst: str) -> bool:
-    if not os.path.exists(dst):
-        return True
-    t = os.path.getmtime(dst)
-    return any(os.path.getmtime(d) > t for d in [src, *_deps(src)] if os.path.exists(d))
+def _digest(src: str, flags) -> str:
+    """content digest of one translation unit: the source, every header it reaches, its flags, the compiler.  Objects are NAMED by
+    it (csrc/_obj/<stem>.<digest>.o), so an object built from other text or other flags can never be linked - mtimes play no part."""
+    h = hashlib.sha256()
+    h.update((" ".join(flags) + "\0" + _hipcc_version()).encode())
+    for f in [src, *sorted(_deps(src))]:
+        h.update(os.path.relpath(f, HERE).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+_HIPCC_VERSION = None
+
+
+def _hipcc_version() -> str:
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+            _HIPCC_VERSION = " ".join(ln.strip() for ln in out.splitlines() if "version" in ln.lower())[:200]
+        except OSError:
+            _HIPCC_VERSION = "unknown"
+    return _HIPCC_VERSION
+
+
+def source_digest() -> str:
+    """digest of everything libcfgpp_hip.so is built from; `cfgpp_build_id()` of a library built from this tree starts with it"""
+    h = hashlib.sha256()
+    for f, extra in SOURCES:
+        h.update(_digest(os.path.join(CSRC, f), COMMON + extra).encode())
+    return h.hexdigest()[:16]
+
+
+def _git_head() -> str:
+    try:
+        root = os.path.dirname(HERE)
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "cfgpp_amd/csrc", "include"], capture_output=True,
+                               text=True).stdout.strip()
+        return (head or "nogit") + ("+local" if dirty else "")
+    except OSError:
+        return "nogit"
+
+
+def library_build_id(path: str = OUT) -> str:
+    """the `cfgpp_build_id()` string of a built library, read from the file (no dlopen): '' when absent"""
+    try:
+        data = open(path, "rb").read()
+    except OSError:
+        return ""
+    i = data.find(b"cfgpp-build:")
+    return data[i:data.index(b"\0", i)].decode() if i >= 0 else ""
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    jobs = []
+    jobs, objs = [], []
     for f, extra in SOURCES:
         src = os.path.join(CSRC, f)
-        obj = os.path.join(OBJ, os.path.splitext(f)[0] + ".o")
-        if force or _newer(src, obj):
-            cmd = [hipcc] + COMMON + extra + ["-x", "hip", "-c", src, "-o", obj]
-            jobs.append((f, cmd))
+        stem = os.path.splitext(f)[0]
+        obj = os.path.join(OBJ, f"{stem}.{_digest(src, COMMON + extra)}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            jobs.append((f, [hipcc] + COMMON + extra + ["-x", "hip", "-c", src, "-o", obj]))
 
     def run(job):
         f, cmd = job
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and os.path.exists(cmd[-1]):
+            os.remove(cmd[-1])
         return f, r.returncode, r.stdout + r.stderr
 
     if jobs:
@@ -91,16 +143,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(f"[cfgpp build] {f}: {'ok' if rc == 0 else 'FAILED'}", flush=True)
                 if rc != 0:
                     raise RuntimeError(f"hipcc failed on {f}:\n{log}")
-    objs = [os.path.join(OBJ, os.path.splitext(f)[0] + ".o") for f, _ in SOURCES]
-    if force or jobs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    keep = set(objs)
+    for old in os.listdir(OBJ):                       # objects of earlier source text
+        if old.endswith(".o") and os.path.join(OBJ, old) not in keep:
+            os.remove(os.path.join(OBJ, old))
+    want = source_digest()
+    have = library_build_id()
+    if force or jobs or not have.startswith(f"cfgpp-build:{want}:"):
+        # the provenance string: <digest of the sources this library is built from>:<git HEAD when it was linked>[+local]
+        bid_src, bid_obj = os.path.join(OBJ, "build_id.cpp"), os.path.join(OBJ, "build_id.o")
+        with open(bid_src, "w") as fh:
+            fh.write('extern "C" const char* cfgpp_build_id(void) { return "cfgpp-build:%s:%s"; }\n' % (want, _git_head()))
+        r = subprocess.run([hipcc, "-O2", "-fPIC", "-c", bid_src, "-o", bid_obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("build_id.cpp failed:\n" + r.stdout + r.stderr)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs + [bid_obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        os.replace(OUT + ".tmp", OUT)
+        os.remove(bid_obj)
         if verbose:
-            print(f"[cfgpp build] linked {OUT}", flush=True)
+            print(f"[cfgpp build] linked {OUT} ({library_build_id()})", flush=True)
     return OUT
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    print(library_build_id())

@@ -26,6 +26,13 @@ from typing import Dict, List, Tuple
 
 import torch
 
+from ._lib import CfgppError
+
+
+# filled by solver_kwargs_from_dir: one line per CLIP tower that fell back from the HIP kernels to the torch-ops tower (callers and
+# tests can assert on it; the GPU tests pin the HIP tower, so a silent fallback would be a different implementation)
+last_text_tower_fallbacks: List[str] = []
+
 
 def _first(*paths):
     for p in paths:
@@ -70,6 +77,9 @@ def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None, t
     on_gpu = torch.device(device).type == "cuda"
     dtype = torch.float16 if on_gpu else torch.float32          # the reference runs the text encoders in the pipeline's fp16
 
+    fallbacks = last_text_tower_fallbacks
+    del fallbacks[:]
+
     def tower(enc, tok, **args):
         e, t = os.path.join(d, enc), os.path.join(d, tok)
         ok = os.path.exists(os.path.join(e, "config.json")) and _weights_in(e, "model") is not None and \
@@ -81,9 +91,12 @@ def solver_kwargs_from_dir(model_dir, sdxl: bool, device="cuda", vae_dir=None, t
             from .text import HipClipTextTower
             try:
                 return HipClipTextTower.from_dir(e, t, device=device, **args)
-            except Exception as exc:  # noqa: BLE001
+            except (CfgppError, KeyError, ValueError, NotImplementedError) as exc:
+                # "this checkpoint is not one the HIP tower takes" (activation, missing / unexpected keys, shapes).  Anything else -
+                # a missing library symbol, a HIP out-of-memory, a bug in the tower - propagates: it must not hide behind a fallback.
                 if text_tower == "hip":
                     raise
+                fallbacks.append(f"{enc}: torch-ops tower ({type(exc).__name__}: {exc})")
                 logging.getLogger("cfgpp_amd").warning("HIP text tower cannot load %s (%s: %s); using the torch-ops ClipTextTower",
                                                        e, type(exc).__name__, exc)
         return ClipTextTower.from_dir(e, t, device=device, dtype=dtype, **args)

@@ -127,6 +127,9 @@ void cfgpp_igemm_walk_plan_probe(int M, int N, int K, int BM, int BN, int smem, 
  * big4_kernel.hip), bit 31 = the tile-walk stage runs.  Default 0xf1ffffff: everything but 25 / 26 / 27, which lose in situ
  * (profiles/r05/ab/) */
 void cfgpp_igemm_set_tune_mask(unsigned mask);
+/* all switches that change what the tuner measures or may pin (mask, big tiles, tail split, walk, staging, forced config),
+ * folded into one word: pins are persisted only by a process whose word is still the default (cfgpp_amd/tune_cache.py) */
+unsigned cfgpp_igemm_tuner_state(void);
 /* 1 (default): on the first cfgpp_unet_forward / cfgpp_vae_decode at a batch size the engine times every igemm
  * launch of its plan in place (HIP events, a few extra forwards, one host sync) per candidate tile config and pins
  * the fastest; results are bit-identical across candidates, K-split launches stay rule-based.  0: fixed heuristic. */

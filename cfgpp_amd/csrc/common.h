@@ -33,6 +33,11 @@ int cfgpp_claim_device(int device_id);      // 0, or -1 (+ error) when the proce
         }                                                                             \
     } while (0)
 
+// whole-step graph replay helpers (step_kernels.hip; used by unet.hip: cfgpp_sample_graph_ddim)
+int step_advance_launch(const float* tab, int* idx, float* cur, hipStream_t s);
+int step_ddim_dev_launch(void* z, void* z0t_out, const void* eps_uc, const void* eps_c, int eps_is_half, int z_is_half, float lam,
+                         const float* cdev, int tweedie_uc, int renoise_uc, long n, hipStream_t s);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- activation layouts -----------------------------------------------------

@@ -1288,7 +1288,7 @@ int launch_cfg_amode(const IGemmArgs& a_in, hipStream_t stream) {
     if (smem > 160 * 1024) {
         // feature maps under 8 x 8 with a time embedding (images under 64 px per side at the bottom level): a big tile spans more
         // batches than its LDS can stage rows for - the 64 x 64 tile (<= 66 rows of 64 floats) always fits
-        if constexpr (WM * WTM > 64 || WN * WTN > 64 || NST != 2) return launch_cfg_amode<2, 2, 32, 32, GLDS, AMODE, 2>(a_in, stream);
+        if constexpr (WM * WTM > 64 || WN * WTN > 64 || NST != 2) { g_last_hint_applied = 0; return launch_cfg_amode<2, 2, 32, 32, GLDS, AMODE, 2>(a_in, stream); }
         else { cfgpp_set_error("igemm: %d time-embedding rows per tile do not fit the LDS", a.par_nb); return -2; }
     }
     static int attr_smem = 0;
@@ -1359,7 +1359,7 @@ int launch_tile32_amode(const IGemmArgs& a_in, hipStream_t stream) {
     a.par_nb = par_slots(a, BM);
     const int nb = a.temb ? (a.par_nb > PAR_NB ? a.par_nb : PAR_NB) : 0;
     const int smem = NST * (BM + BN) * 64 + par_bytes(BN, nb);
-    if (smem > 160 * 1024) return launch_cfg_amode<2, 2, 32, 32, true, AMODE, 2>(a_in, stream);      // (feature maps under 8 x 8: see launch_cfg_amode)
+    if (smem > 160 * 1024) { g_last_hint_applied = 0; return launch_cfg_amode<2, 2, 32, 32, true, AMODE, 2>(a_in, stream); }   // (feature maps under 8 x 8: see launch_cfg_amode; the candidate did not run)
     if (WGS > 1 && smem * WGS > 160 * 1024) {
         // more time-embedding rows than the 2 - 3 workgroups per CU were sized for (small feature maps): the config would run
         // in a regime it was not built for - take the 128 x 128 tile and tell the tuner that the candidate did not run
@@ -1415,7 +1415,7 @@ int launch_mf16_amode(const IGemmArgs& a_in, hipStream_t stream) {
     IGemmArgs a = a_in;
     a.par_nb = par_slots(a, 128);
     const int smem = NST * (128 + 160) * 128 + par_bytes(160, a.par_nb > PAR_NB ? a.par_nb : PAR_NB);
-    if (smem > 160 * 1024) return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2>(a_in, stream);   // (feature maps under 8 x 8: see launch_cfg_amode)
+    if (smem > 160 * 1024) { g_last_hint_applied = 0; return launch_cfg_amode<4, 1, 32, 160, true, AMODE, 2>(a_in, stream); }   // (feature maps under 8 x 8: see launch_cfg_amode)
     static int attr_smem = 0;
     auto kern = igemm16_kernel<AMODE, NST>;
     if (smem > attr_smem) {
@@ -1569,6 +1569,12 @@ int igemm_autotune_enabled() { return g_autotune && g_force_cfg == 0 && g_stagin
 static unsigned g_tune_mask = 0xf1ffffffu;
 extern "C" void cfgpp_igemm_set_tune_mask(unsigned mask) { g_tune_mask = mask; }
 unsigned igemm_tune_mask() { return g_tune_mask; }
+// every switch that changes what the tuner measures or may pin, folded into one word: the Python pin cache persists pins only
+// while this still has the value it had when the engine was built (cfgpp_amd/tune_cache.py)
+extern "C" unsigned cfgpp_igemm_tuner_state(void) {
+    return g_tune_mask ^ ((unsigned)g_big_tiles << 1) ^ ((unsigned)g_tail_split << 3) ^ ((unsigned)(g_n_major + 1) << 6) ^ ((unsigned)g_walk_blocked << 9) ^
+           ((unsigned)g_staged_epi << 10) ^ ((unsigned)g_force_cfg << 12) ^ ((unsigned)g_staging << 20);
+}
 
 // Arms the timeline: the `target`-th igemm_launch call from now on (0-based) records 16 x uint64 per workgroup (slots: see
 // IGemmArgs::tl) into buf[grid][16] (device memory, >= cap_blocks * 128 bytes; launches with more workgroups than cap_blocks

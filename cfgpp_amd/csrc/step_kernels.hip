@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(256)
 ddim_step_kernel(float* __restrict__ z, float* __restrict__ z0t_out,
                  const void* __restrict__ eps_uc_, const void* __restrict__ eps_c_,
                  float lam, float c1, float c2, float c3, float c4,
-                 int tweedie_uc, int renoise_uc, long n4) {
+                 int tweedie_uc, int renoise_uc, long n4, const float* __restrict__ cdev) {
+    if (cdev) { c1 = cdev[0]; c2 = cdev[1]; c3 = cdev[2]; c4 = cdev[3]; }      // graph replay: this step's scalars (same fp32 values)
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
@@ -95,7 +96,8 @@ __global__ void __launch_bounds__(256)
 ddim_step_h_kernel(half_t* __restrict__ z, half_t* __restrict__ z0t_out,
                    const half_t* __restrict__ eps_uc, const half_t* __restrict__ eps_c,
                    float lam, float c1, float c2, float c3, float c4,
-                   int tweedie_uc, int renoise_uc, long n4) {
+                   int tweedie_uc, int renoise_uc, long n4, const float* __restrict__ cdev) {
+    if (cdev) { c1 = cdev[0]; c2 = cdev[1]; c3 = cdev[2]; c4 = cdev[3]; }
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
@@ -241,10 +243,10 @@ int cfgpp_step_ddim(void* z, void* z0t_out, const void* eps_uc, const void* eps_
     hipStream_t s = (hipStream_t)stream;
     if (eps_is_half)
         hipLaunchKernelGGL(ddim_step_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, s, (float*)z, (float*)z0t_out,
-                           eps_uc, eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4);
+                           eps_uc, eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4, (const float*)nullptr);
     else
         hipLaunchKernelGGL(ddim_step_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, s, (float*)z, (float*)z0t_out,
-                           eps_uc, eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4);
+                           eps_uc, eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4, (const float*)nullptr);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -256,10 +258,48 @@ int cfgpp_step_ddim_h(void* z, void* z0t_out, const void* eps_uc, const void* ep
     CFGPP_REQUIRE(z && z0t_out && eps_uc && eps_c, "cfgpp_step_ddim_h: null pointer");
     const long n4 = n / 4;
     hipLaunchKernelGGL(ddim_step_h_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (half_t*)z, (half_t*)z0t_out,
-                       (const half_t*)eps_uc, (const half_t*)eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4);
+                       (const half_t*)eps_uc, (const half_t*)eps_c, lam, c1, c2, c3, c4, tweedie_uc, renoise_uc, n4, (const float*)nullptr);
     CFGPP_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+}  // extern "C"
+
+// ---- whole-step graph replay (unet.hip: cfgpp_sample_graph_ddim) ------------------------------------------------------------
+// A captured step cannot take its scalars as kernel arguments (they are baked at capture), so the graph's first node copies row
+// *idx of the per-step table [n][8] = {t, c1, c2, c3, c4, -, -, -} into `cur` and advances *idx; the timestep sinusoid reads
+// cur[0], the step kernel cur[1..4].  Same fp32 values as the eager path's arguments -> bit-identical latents.
+__global__ void step_advance_kernel(const float* __restrict__ tab, int* __restrict__ idx, float* __restrict__ cur) {
+    const int i = *idx;
+    if (threadIdx.x < 8) cur[threadIdx.x] = tab[(long)i * 8 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) *idx = i + 1;
+}
+int step_advance_launch(const float* tab, int* idx, float* cur, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, tab, idx, cur);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// the generalised DDIM update with c1..c4 read from cdev[0..3] (device memory)
+int step_ddim_dev_launch(void* z, void* z0t_out, const void* eps_uc, const void* eps_c, int eps_is_half, int z_is_half, float lam,
+                         const float* cdev, int tweedie_uc, int renoise_uc, long n, hipStream_t s) {
+    CFGPP_REQUIRE(n > 0 && (n % 4) == 0 && z && z0t_out && eps_uc && eps_c && cdev, "step_ddim_dev: bad args");
+    CFGPP_REQUIRE(!z_is_half || eps_is_half, "step_ddim_dev: an fp16 latent needs fp16 eps");
+    const long n4 = n / 4;
+    if (z_is_half)
+        hipLaunchKernelGGL(ddim_step_h_kernel, dim3(grid_for(n4)), dim3(256), 0, s, (half_t*)z, (half_t*)z0t_out, (const half_t*)eps_uc,
+                           (const half_t*)eps_c, lam, 0.f, 1.f, 0.f, 0.f, tweedie_uc, renoise_uc, n4, cdev);
+    else if (eps_is_half)
+        hipLaunchKernelGGL(ddim_step_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, s, (float*)z, (float*)z0t_out, eps_uc, eps_c,
+                           lam, 0.f, 1.f, 0.f, 0.f, tweedie_uc, renoise_uc, n4, cdev);
+    else
+        hipLaunchKernelGGL(ddim_step_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, s, (float*)z, (float*)z0t_out, eps_uc, eps_c,
+                           lam, 0.f, 1.f, 0.f, 0.f, tweedie_uc, renoise_uc, n4, cdev);
+    CFGPP_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
 
 int cfgpp_kdiff_input(const void* x, void* xc, float s, int mode, long n, void* stream) {
     CFGPP_REQUIRE(n > 0 && x && xc, "cfgpp_kdiff_input: bad args");

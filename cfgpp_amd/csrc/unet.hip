@@ -19,6 +19,17 @@ struct cfgpp_unet : EngineBase {
     std::vector<Op> ctx_plan;       // set_context (cross-attention K/V, added-condition embedding)
     // forward-time inputs (pointers patched per call)
     const void* in_z = nullptr; int in_z_half = 0; int in_z_rows = 0; float in_t = 0.f; void* out_eps = nullptr;
+    const float* in_t_dev = nullptr;        // non-null: the timestep sinusoid reads *in_t_dev (graph replay) instead of in_t
+    // whole-step graph replay (cfgpp_sample_graph_ddim): per-step scalar table, current-step block, step counter, the one cached graph
+    float* d_step_tab = nullptr; int step_tab_cap = 0; float* d_step_cur = nullptr; int* d_step_idx = nullptr;
+    hipStream_t cap_stream = nullptr;
+    struct GraphKey { const void* z; void* z0t; void* eps; const void* euc; const void* ec; int z_half, z_rows, rows, tw, rn; float lam; long n; int tuned_serial; };
+    struct Graph { GraphKey key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<Graph> graphs;              // most recently used last; at most 4 (an invert + edit job alternates between two)
+    int tuned_serial = 0;                   // bumps whenever the pins of the current batch change (a graph bakes the tiles it captured)
+    static void destroy(Graph& g) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); g.exec = nullptr; g.graph = nullptr; }
+    void drop_graphs() { for (auto& g : graphs) destroy(g); graphs.clear(); }
+    ~cfgpp_unet() { drop_graphs(); if (cap_stream) hipStreamDestroy(cap_stream); }
     // context inputs
     const half_t* ctx_ehs = nullptr; int ctx_rows = 0; int ctx_tokens = 77;
     const half_t* ctx_text = nullptr; const float* ctx_tids = nullptr; int ctx_cond_rows = 0;
@@ -244,7 +255,7 @@ int cfgpp_unet_finalize(cfgpp_unet* u) {
         half_t* w1 = B.linear("time_embedding.linear_1.weight"); float* b1 = B.f32("time_embedding.linear_1.bias");
         half_t* w2 = B.linear("time_embedding.linear_2.weight"); float* b2 = B.f32("time_embedding.linear_2.bias");
         cfgpp_unet* uu = u;
-        u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_sinusoid(nullptr, uu->in_t, uu->d_sin_t, 1, c0, c0, 0, s); });
+        u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_sinusoid(uu->in_t_dev, uu->in_t, uu->d_sin_t, 1, c0, c0, 0, s); });
         u->plan.push_back([=](hipStream_t s, int) { return cfgpp_op_skinny_gemm(uu->d_sin_t, c0, w1, b1, nullptr, 0, uu->d_emb_h, temb_dim, 1, temb_dim, c0, 0, 1, s); });
         if (per_row_temb) {
             // emb[r] = linear_2(h) + aug[r or 0]
@@ -503,11 +514,93 @@ int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, 
     CFGPP_REQUIRE(u->ctx_set, "forward: set_context has not been called");
     CFGPP_REQUIRE(z && eps_out && z_rows > 0 && rows > 0 && rows <= u->cfg.max_rows, "forward: bad args (rows=%d max=%d)", rows, u->cfg.max_rows);
     CFGPP_REQUIRE(rows == u->ctx_rows, "forward: rows=%d but context was set for %d rows", rows, u->ctx_rows);
-    u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->out_eps = eps_out;
+    u->in_z = z; u->in_z_half = z_is_half; u->in_z_rows = z_rows; u->in_t = t; u->in_t_dev = nullptr; u->out_eps = eps_out;
     if (u->tuned_rows != rows && igemm_autotune_enabled()) {      // first forward at this batch: in-situ tile tuning
         int e = u->tune_plan((hipStream_t)stream, rows); if (e) return e;
+        ++u->tuned_serial;
     }
     for (auto& op : u->plan) { int e = op((hipStream_t)stream, rows); if (e) return e; }
+    return 0;
+}
+
+// Whole-loop graph replay: the reference's DDIM loops with callback_fn None
+// (latent_diffusion.py:653-674, 272-294, 160-182; latent_sdxl.py:730-752, 838-858) as ONE captured step - UNet forward at `rows` +
+// the fused generalised DDIM update - replayed n_steps times.  The per-step scalars {t, c1, c2, c3, c4} (host_steps[n_steps][5],
+// the same fp32 values cfgpp_unet_forward / cfgpp_step_ddim take as arguments) go into a device table; the graph's first node
+// copies the current row and advances a device counter, so one graph serves every step and every later call with the same
+// buffers.  z / z0t [z_rows,4,H,W] fp32 or fp16 (updated in place / written per step), eps [rows,4,H,W] fp16 scratch the UNet
+// writes, eps_uc / eps_c point into it.  Capture happens on an engine-owned stream (the caller's may be the legacy default
+// stream, which cannot capture) after one eager forward (tile tuning, lazy kernel attributes); replays are enqueued on `stream`.
+// Results are bit-identical to the eager loop.  Returns 0, < 0 on error (a failed capture leaves no graph behind).
+int cfgpp_sample_graph_ddim(cfgpp_unet* u, void* z, void* z0t, int z_is_half, int z_rows, void* eps, const void* eps_uc,
+                            const void* eps_c, int rows, const float* host_steps, int n_steps, float lam, int tweedie_uc,
+                            int renoise_uc, void* stream) {
+    CFGPP_REQUIRE(u && u->finalized && u->ctx_set, "sample_graph: context not ready");
+    CFGPP_REQUIRE(z && z0t && eps && eps_uc && eps_c && host_steps && n_steps > 0 && z_rows > 0, "sample_graph: bad args");
+    CFGPP_REQUIRE(rows == u->ctx_rows && rows <= u->cfg.max_rows, "sample_graph: rows=%d but context was set for %d rows", rows, u->ctx_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)z_rows * u->cfg.in_channels * u->cfg.sample_h * u->cfg.sample_w;
+    if (!u->d_step_cur) {
+        u->d_step_cur = (float*)u->dmalloc(8 * sizeof(float));
+        u->d_step_idx = (int*)u->dmalloc(sizeof(int));
+        CFGPP_REQUIRE(u->d_step_cur && u->d_step_idx, "sample_graph: out of device memory");
+        CFGPP_HIP_CHECK(hipStreamCreateWithFlags(&u->cap_stream, hipStreamNonBlocking));
+    }
+    if (n_steps > u->step_tab_cap) {
+        u->drop_graphs();                                         // the graphs hold the old table's address
+        const int cap = n_steps < 64 ? 64 : n_steps;
+        u->d_step_tab = (float*)u->dmalloc((size_t)cap * 8 * sizeof(float));   // (the old table is freed with the engine)
+        CFGPP_REQUIRE(u->d_step_tab, "sample_graph: out of device memory");
+        u->step_tab_cap = cap;
+    }
+    const cfgpp_unet::GraphKey want{z, z0t, eps, eps_uc, eps_c, z_is_half, z_rows, rows, tweedie_uc, renoise_uc, lam, n, 0};
+    auto same = [&](const cfgpp_unet::GraphKey& k) {
+        return k.z == want.z && k.z0t == want.z0t && k.eps == want.eps && k.euc == want.euc && k.ec == want.ec && k.z_half == want.z_half &&
+               k.z_rows == want.z_rows && k.rows == want.rows && k.tw == want.tw && k.rn == want.rn && k.lam == want.lam && k.n == want.n &&
+               k.tuned_serial == u->tuned_serial;
+    };
+    int hit = -1;
+    for (size_t i = 0; i < u->graphs.size(); ++i) if (same(u->graphs[i].key)) hit = (int)i;
+    if (hit < 0) {
+        // eager first: tile tuning (bumps tuned_serial), kernel attributes and every other lazy host-side initialisation happen
+        // outside the capture.  The forward only reads z, so the loop below starts from the same state.
+        int e = cfgpp_unet_forward(u, z, z_is_half, z_rows, host_steps[0], eps, rows, stream);
+        if (e) return e;
+        CFGPP_HIP_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < u->graphs.size();)                 // graphs of other pins can never hit again
+            if (u->graphs[i].key.tuned_serial != u->tuned_serial) { cfgpp_unet::destroy(u->graphs[i]); u->graphs.erase(u->graphs.begin() + i); } else ++i;
+        cfgpp_unet::Graph g{want, nullptr, nullptr};
+        g.key.tuned_serial = u->tuned_serial;
+        u->in_t_dev = u->d_step_cur;
+        hipError_t he = hipStreamBeginCapture(u->cap_stream, hipStreamCaptureModeRelaxed);
+        int rc = 0;
+        if (he == hipSuccess) {
+            rc = step_advance_launch(u->d_step_tab, u->d_step_idx, u->d_step_cur, u->cap_stream);
+            for (size_t i = 0; i < u->plan.size() && rc == 0; ++i) rc = u->plan[i](u->cap_stream, rows);
+            if (rc == 0) rc = step_ddim_dev_launch(z, z0t, eps_uc, eps_c, 1, z_is_half, lam, u->d_step_cur + 1, tweedie_uc, renoise_uc, n, u->cap_stream);
+            he = hipStreamEndCapture(u->cap_stream, &g.graph);
+        }
+        u->in_t_dev = nullptr;
+        if (he != hipSuccess || rc != 0 || !g.graph) {
+            cfgpp_unet::destroy(g);
+            if (rc == 0) cfgpp_set_error("sample_graph: stream capture failed: %s", hipGetErrorString(he));
+            return rc ? rc : -1;
+        }
+        he = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+        if (he != hipSuccess) { cfgpp_unet::destroy(g); cfgpp_set_error("sample_graph: hipGraphInstantiate: %s", hipGetErrorString(he)); return -1; }
+        if (u->graphs.size() >= 4) { cfgpp_unet::destroy(u->graphs.front()); u->graphs.erase(u->graphs.begin()); }
+        u->graphs.push_back(g);
+        hit = (int)u->graphs.size() - 1;
+    }
+    if (hit != (int)u->graphs.size() - 1) std::swap(u->graphs[hit], u->graphs.back());
+    hipGraphExec_t exec = u->graphs.back().exec;
+    // this call's table (pageable host memory: the copy is staged, the buffer is free when the call returns) and counter
+    std::vector<float> tab((size_t)n_steps * 8, 0.f);
+    for (int i = 0; i < n_steps; ++i) for (int k = 0; k < 5; ++k) tab[(size_t)i * 8 + k] = host_steps[(size_t)i * 5 + k];
+    CFGPP_HIP_CHECK(hipMemcpyAsync(u->d_step_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    CFGPP_HIP_CHECK(hipStreamSynchronize(s));        // `tab` leaves scope; once per sampling loop
+    CFGPP_HIP_CHECK(hipMemsetAsync(u->d_step_idx, 0, sizeof(int), s));
+    for (int i = 0; i < n_steps; ++i) CFGPP_HIP_CHECK(hipGraphLaunch(exec, s));
     return 0;
 }
 
@@ -561,6 +654,7 @@ int cfgpp_unet_tuning(cfgpp_unet* u, int rows, int* hints, int cap, int set) {
     if (set) {
         u->tuned_by_rows[rows] = std::vector<int>(hints, hints + n);
         if (u->tuned_rows == rows) u->tuned_rows = 0;      // re-install on the next forward
+        ++u->tuned_serial;
         return n;
     }
     auto it = u->tuned_by_rows.find(rows);

@@ -224,6 +224,26 @@ class HipUNet:
                                           eps_out.data_ptr(), rows, _stream_ptr(z)), "cfgpp_unet_forward")
         return eps_out
 
+    def sample_graph_ddim(self, z: torch.Tensor, z0t: torch.Tensor, eps: torch.Tensor, eps_uc: torch.Tensor, eps_c: torch.Tensor,
+                          steps, lam: float, tweedie_uc: bool, renoise_uc: bool):
+        """the whole DDIM loop as hipGraph replays (include/cfgpp.h: cfgpp_sample_graph_ddim).  ``steps``: per step
+        ``(t, c1, c2, c3, c4)`` - what the eager loop passes to ``forward`` and ``step_ddim``; z is updated in place."""
+        for n, t in (("z", z), ("z0t", z0t), ("eps", eps)):
+            _require_cuda(t, n)
+        if z.dtype != z0t.dtype or z.dtype not in (torch.float16, torch.float32) or eps.dtype != torch.float16:
+            raise CfgppError("sample_graph_ddim: z / z0t must both be fp32 or both fp16, eps fp16")
+        if tuple(z.shape[1:]) != (self.cfg.in_channels, self.H, self.W) or z.shape != z0t.shape:
+            raise CfgppError(f"sample_graph_ddim: z shape {tuple(z.shape)}")
+        if int(eps.shape[0]) != self.rows or self.rows % int(z.shape[0]) != 0:
+            raise CfgppError(f"sample_graph_ddim: eps rows {int(eps.shape[0])} / z rows {int(z.shape[0])} vs context rows {self.rows}")
+        flat = [float(v) for st in steps for v in st]
+        if len(flat) != 5 * len(steps) or not steps:
+            raise CfgppError("sample_graph_ddim: steps must be a non-empty list of (t, c1, c2, c3, c4)")
+        arr = (C.c_float * len(flat))(*flat)
+        check(self.lib.cfgpp_sample_graph_ddim(self._h, z.data_ptr(), z0t.data_ptr(), 1 if z.dtype == torch.float16 else 0, int(z.shape[0]),
+                                               eps.data_ptr(), eps_uc.data_ptr(), eps_c.data_ptr(), self.rows, arr, len(steps), float(lam),
+                                               int(bool(tweedie_uc)), int(bool(renoise_uc)), _stream_ptr(z)), "cfgpp_sample_graph_ddim")
+
     def profile(self, z: torch.Tensor, t: float, detail: bool = False) -> dict:
         """One forward with HIP events between launches: per kernel family ms / algorithmic flops / launches."""
         _require_cuda(z, "z")

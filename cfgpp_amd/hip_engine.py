@@ -54,9 +54,11 @@ class HipEngine:
         self.H, self.W = self.unet.H, self.unet.W
         # tile pins persist across processes (tune_cache.py): only the first process on a box runs the in-situ tuning passes
         self._pins = PinCache(getattr(cfg, "name", type(cfg).__name__), (self.H, self.W), torch.cuda.get_device_properties(self.device).name,
-                              build_id(_lib.LIB_PATH), lambda rows: self.unet.export_tuning(rows), lambda h, rows: self.unet.import_tuning(h, rows))
+                              build_id(_lib.LIB_PATH), lambda rows: self.unet.export_tuning(rows), lambda h, rows: self.unet.import_tuning(h, rows),
+                              knobs=lambda: (int(self.unet.lib.cfgpp_igemm_tuner_state()),))
         self._ctx_key = None
         self._eps = None
+        self._g_buf = None
         # opt-in guard for the first runs with a real checkpoint (real SDXL activations approach the fp16 maximum in the deep
         # blocks; the synthetic weights of the tests do not): scan eps after every forward - one host sync per step - and stop
         # with the timestep instead of decoding a NaN image
@@ -82,7 +84,8 @@ class HipEngine:
         self.unet.set_context(ehs, text_embeds, time_ids)
         self._pins.load(2 * B)
         self.B = B
-        self._eps = torch.empty((2 * B, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=self.device)
+        if self._eps is None or int(self._eps.shape[0]) != 2 * B:      # kept across calls: a captured graph holds its address
+            self._eps = torch.empty((2 * B, self.cfg.out_channels, self.H, self.W), dtype=torch.float16, device=self.device)
 
     def predict(self, z: torch.Tensor, t: float):
         """(eps_uc, eps_c), each [B,4,H,W] fp16 - replaces predict_noise's UNet call + chunk(2)."""
@@ -92,12 +95,39 @@ class HipEngine:
             self._finite_or_raise(t)
         return eps[: self.B], eps[self.B:]
 
+    # -- whole-loop graph replay ---------------------------------------------------------
+    @property
+    def graph_enabled(self) -> bool:
+        """$CFGPP_GRAPH=1: DDIM loops without a callback run as hipGraph replays of one captured step (default off: see DESIGN.md)"""
+        return os.environ.get("CFGPP_GRAPH", "0") not in ("", "0")
+
+    def ddim_loop_graph(self, zt: torch.Tensor, steps, lam: float, tweedie_uc: bool, renoise_uc: bool, single: str = ""):
+        """run the whole loop on (a persistent copy of) ``zt``; returns (z0t, zt) as fresh tensors.  ``single``: "uc" / "c" when the
+        caller passed only one conditioning (both eps halves are then the same rows, like predict_noise's)"""
+        key = (int(zt.shape[0]), zt.dtype)
+        if self._g_buf is None or self._g_buf[0] != key:
+            self._g_buf = (key, torch.empty_like(zt), torch.empty_like(zt))      # stable addresses: one capture serves every sample() call
+        _, gz, gz0 = self._g_buf
+        gz.copy_(zt)
+        eps = self._eps
+        euc, ec = eps[: self.B], eps[self.B:]
+        if single == "uc":
+            ec = euc
+        elif single == "c":
+            euc = ec
+        self.unet.sample_graph_ddim(gz, gz0, eps, euc, ec, steps, lam, tweedie_uc, renoise_uc)
+        self._pins.save(self.unet.rows)
+        if self.check_finite:
+            self._finite_or_raise(steps[-1][0])
+        return gz0.clone(), gz.clone()
+
     # -- tile pins (bench.py: rank 0 tunes, every rank imports) ----
     def export_tuning(self):
         return self.unet.export_tuning(self.unet.rows)
 
     def import_tuning(self, hints, batch: int):
         self.unet.import_tuning(hints, 2 * int(batch))
+        self._pins.mark_imported(2 * int(batch))       # an explicit import wins over whatever this rank's disk cache holds
 
     def device_bytes(self) -> float:
         return self.unet.device_bytes()

@@ -138,6 +138,16 @@ class StableDiffusion:
     def predict_noise(self, zt: torch.Tensor, t, uc: Optional[torch.Tensor], c: Optional[torch.Tensor]):
         """epsilon_theta for null and condition (latent_diffusion.py:131-158).  One
         UNet launch over rows [uc_1..uc_B, c_1..c_B]; ``zt`` is read twice by index."""
+        self._ensure_context(uc, c)
+        noise_uc, noise_c = self.engine.predict(zt, float(t))
+        if uc is None:
+            return noise_c, noise_c
+        if c is None:
+            return noise_uc, noise_uc
+        return noise_uc, noise_c
+
+    def _ensure_context(self, uc, c):
+        """(re)build the engine's conditioning when the embeddings changed (once per sampling loop)"""
         if uc is None and c is None:
             raise ValueError("predict_noise needs at least one of uc / c")
         a = c if uc is None else uc
@@ -147,12 +157,23 @@ class StableDiffusion:
             self._set_context(a, b)
             self._ctx_key = key
             self._ctx_keep = (a, b)
-        noise_uc, noise_c = self.engine.predict(zt, float(t))
-        if uc is None:
-            return noise_c, noise_c
-        if c is None:
-            return noise_uc, noise_uc
-        return noise_uc, noise_c
+
+    # ------------------------------------------------------------------ whole-loop graph replay
+    def _graph_loop(self, zt, ts, uc, c, lam, tweedie_uc, renoise_uc, coeff_of):
+        """The DDIM loops with callback_fn None as hipGraph replays of ONE captured step (UNet + fused update; include/cfgpp.h:
+        cfgpp_sample_graph_ddim) when the engine offers it ($CFGPP_GRAPH=1 on the HIP engine): the per-step scalars - exactly
+        what the eager loop hands to ``predict`` / ``step_ddim`` - are computed up front.  ``coeff_of(t) -> (sqrt4, device_alpha)``.
+        Returns (z0t, zt) or None when the eager loop has to run (mock engine, switch off)."""
+        if not getattr(self.engine, "graph_enabled", False):
+            return None
+        z_half = zt.dtype == torch.float16
+        steps = []
+        for t in ts:
+            sqrt4, dev_a = coeff_of(t)
+            co = K.ddim_coeffs_pinned(sqrt4, eps_half=True, semantics=self.scalar_semantics, z_half=z_half, device_alpha=dev_a)
+            steps.append((float(t), *[float(v) for v in co]))
+        single = "c" if uc is None else ("uc" if c is None else "")
+        return self.engine.ddim_loop_graph(zt, steps, lam, tweedie_uc, renoise_uc, single)
 
     def _set_context(self, uc, c):
         self.engine.set_context(uc, c)
@@ -228,9 +249,15 @@ class StableDiffusion:
         ``zt`` [B,4,H,W] on the engine device: fp32 (text-to-image: ``torch.randn``) or fp16 (after an
         inversion that started from the fp16 VAE latent); a private copy is updated in place; returns (z0t, zt)."""
         zt = self._own_latent(zt)
-        z0t = torch.empty_like(zt)
         ts = self.scheduler.timesteps
         ts = ts.int() if wrap_index else ts
+        if callback_fn is None:
+            self._ensure_context(uc, c)
+            done = self._graph_loop(zt, ts, uc, c, cfg_guidance, False, cfgpp, lambda t: (
+                self.tables.ddim_sqrt_coeffs(t, wrap=wrap_index), "rn" if (not wrap_index and int(t) - self.tables.skip < 0) else None))
+            if done is not None:
+                return done
+        z0t = torch.empty_like(zt)
         for step, t in enumerate(_progress(ts, desc)):
             # at = alpha(t), at_prev = alpha(t - skip); SDXL loops index the shifted table
             # unguarded (quirk Q3, wrap_index).  sqrt(at) etc. come from the pinned tables.
@@ -246,6 +273,11 @@ class StableDiffusion:
     def _ddim_inversion(self, z0, uc, c, cfg_guidance, cfgpp: bool):
         """DDIM inversion (latent_diffusion.py:160-182 CFG, 888-910 CFG++)."""
         zt = self._own_latent(z0)
+        self._ensure_context(uc, c)
+        done = self._graph_loop(zt, list(reversed(self.scheduler.timesteps)), uc, c, cfg_guidance, cfgpp, False, lambda t: (
+            self.tables.ddim_sqrt_coeffs(t, inversion=True), "tw" if int(t) - self.tables.skip < 0 else None))
+        if done is not None:
+            return done[1]
         z0t = torch.empty_like(zt)
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM Inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)     # a_tw = alpha(t-skip), a_rn = alpha(t)

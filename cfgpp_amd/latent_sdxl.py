@@ -91,6 +91,15 @@ class SDXL(StableDiffusion):
     # ------------------------------------------------------------------ UNet
     def predict_noise(self, zt, t, uc, c, added_cond_kwargs):
         """reference: latent_sdxl.py:167-185."""
+        self._ensure_context(uc, c, added_cond_kwargs)
+        noise_uc, noise_c = self.engine.predict(zt, float(t))
+        if uc is None:
+            return noise_c, noise_c
+        if c is None:
+            return noise_uc, noise_uc
+        return noise_uc, noise_c
+
+    def _ensure_context(self, uc, c, added_cond_kwargs):
         if uc is None and c is None:
             raise ValueError("predict_noise needs at least one of uc / c")
         a = c if uc is None else uc
@@ -109,12 +118,6 @@ class SDXL(StableDiffusion):
             self.engine.set_context(a, b, te_full, ti_full)
             self._ctx_key = key
             self._ctx_keep = (a, b, te, ti)
-        noise_uc, noise_c = self.engine.predict(zt, float(t))
-        if uc is None:
-            return noise_c, noise_c
-        if c is None:
-            return noise_uc, noise_uc
-        return noise_uc, noise_c
 
     # ------------------------------------------------------------------ sample
     def _sizes(self, original_size, target_size):
@@ -202,6 +205,11 @@ class SDXL(StableDiffusion):
     def _inversion_xl(self, z0, uc, c, cfg_guidance, add_cond_kwargs, cfgpp):
         self._split_cond_for_inversion(cfg_guidance, add_cond_kwargs)
         zt = self._own_latent(z0)
+        self._ensure_context(uc, c, add_cond_kwargs)
+        done = self._graph_loop(zt, list(reversed(self.scheduler.timesteps)), uc, c, cfg_guidance, cfgpp, False, lambda t: (
+            self.tables.ddim_sqrt_coeffs(t, inversion=True), "tw" if int(t) - self.tables.skip < 0 else None))
+        if done is not None:
+            return done[1]
         z0t = torch.empty_like(zt)
         for t in _progress(reversed(self.scheduler.timesteps), "DDIM inversion"):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, inversion=True)
@@ -226,8 +234,14 @@ class SDXL(StableDiffusion):
         if zt is None:
             zt = self.initialize_latent(size=self._latent_size(shape), seeds=seeds)
         zt = self._own_latent(zt)
-        z0t = torch.empty_like(zt)
         ts = self.scheduler.timesteps.int() if wrap else self.scheduler.timesteps
+        if callback_fn is None:
+            self._ensure_context(null_e, emb, add_cond_kwargs)
+            done = self._graph_loop(zt, ts, null_e, emb, cfg_guidance, False, cfgpp, lambda t: (
+                self.tables.ddim_sqrt_coeffs(t, wrap=wrap), "rn" if (not wrap and int(t) - self.tables.skip < 0) else None))
+            if done is not None:
+                return done[0]
+        z0t = torch.empty_like(zt)
         for step, t in enumerate(_progress(ts, desc)):
             sqrt4 = self.tables.ddim_sqrt_coeffs(t, wrap=wrap)
             noise_uc, noise_c = self.predict_noise(zt, t, null_e, emb, add_cond_kwargs)

@@ -33,6 +33,11 @@ extern "C" {
 
 const char* cfgpp_last_error(void);
 
+/* Provenance of this binary (no reference counterpart): "cfgpp-build:<digest of the kernel sources + flags it was compiled
+ * from>:<git HEAD when it was linked>[+local]".  cfgpp_amd/build.py names every object file by the same digests, so a stale
+ * object cannot be linked; bench.py, smoke() and the real-size GPU tests print this string next to their numbers. */
+const char* cfgpp_build_id(void);
+
 /* ---- fused sampler step (K12) ------------------------------------------- */
 
 /* Generalised DDIM update on n fp32 latent elements, in place:
@@ -131,6 +136,21 @@ int cfgpp_unet_set_context(cfgpp_unet* u, const void* ehs, int rows, int tokens,
  * latent_diffusion.py:153-156: eps_uc = eps[0:z_rows], eps_c = eps[z_rows:]. */
 int cfgpp_unet_forward(cfgpp_unet* u, const void* z, int z_is_half, int z_rows, float t,
                        void* eps_out, int rows, void* stream);
+
+/* Whole-loop hipGraph replay: the reference's DDIM loops when callback_fn is None (latent_diffusion.py:653-674, 272-294,
+ * 160-182, 888-910; latent_sdxl.py:730-752, 838-858) as ONE captured step - the UNet forward at `rows` plus the fused
+ * generalised DDIM update of cfgpp_step_ddim / cfgpp_step_ddim_h - replayed n_steps times on `stream`.
+ * host_steps[n_steps][5] = {t, c1, c2, c3, c4} per step: exactly the values the eager loop would pass to
+ * cfgpp_unet_forward and cfgpp_step_ddim (HOST memory, copied before the call returns); they live in a device table
+ * indexed by a device step counter, so one graph serves every step and every later call with the same buffers (the
+ * engine keeps the most recent graph; other buffers / flags / batch re-capture).  z, z0t: [z_rows][in_ch][H][W] fp32 or
+ * fp16 (z updated in place, z0t written every step); eps: [rows][out_ch][H][W] fp16 scratch for the UNet output;
+ * eps_uc / eps_c point into it (the same pointer for the lambda == 1 Lightning form).  The first call at a batch runs one
+ * eager forward (tile tuning, see above) and captures on an engine-owned stream - `stream` may be the legacy default
+ * stream.  One host sync per call (the table upload), none per step.  Latents are bit-identical to the eager loop. */
+int cfgpp_sample_graph_ddim(cfgpp_unet* u, void* z, void* z0t, int z_is_half, int z_rows, void* eps, const void* eps_uc,
+                            const void* eps_c, int rows, const float* host_steps, int n_steps, float lam, int tweedie_uc,
+                            int renoise_uc, void* stream);
 
 /* Same forward with a HIP event between every launch (on `stream`): per kernel family
  * k = 0 implicit-GEMM conv/linear, 1 attention, 2 GroupNorm/LayerNorm, 3 small ops:

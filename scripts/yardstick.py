@@ -1,0 +1,192 @@
+"""Same-box vendor yardstick (MEASUREMENT ONLY - nothing here is on the product path): the dominant GEMM / convolution /
+attention shapes of the SD1.5 (16 rows) and SDXL (4 rows) forwards, timed in ONE process on ONE MI355X, alternating between
+
+  * ours:    the library's own kernels through the single-op test hooks (cfgpp_op_igemm / cfgpp_op_attention): the heuristic tile
+             (what an un-tuned launch runs) and the best of the tuner's candidate tiles (what the in-situ tuner can pin),
+  * vendor:  torch.nn.functional.linear (hipBLASLt / rocBLAS), F.conv2d on channels_last fp16 (MIOpen) and
+             F.scaled_dot_product_attention (the ROCm flash / mem-efficient / math kernels), all fp16.
+
+    python scripts/yardstick.py [--out profiles/r06/yardstick.json] [--iters 30] [--filter substr]
+
+Both sides get the same problem: hot caches, the same number of back-to-back launches between two events on torch's current
+stream, best of 3 repetitions, order alternated ours / vendor / ours / vendor.  TF/s are ALGORITHMIC (2*M*N*K; attention
+4*B*h*Nq*Nk*d), so a vendor kernel that pads or a kernel of ours that pads are both charged for it.
+What the vendor column does NOT include, and ours does: the fused epilogues (bias, residual, GEGLU's erf-GELU gate and halved
+output, head-major Q/K/V^T scatter, time-embedding add, GroupNorm statistics) - the vendor GEMM writes a plain fp16 C.  For GEGLU
+the vendor side is the plain M x 2F x K GEMM (no gate), ours is the fused launch, flops counted alike.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import hip_ops as H  # noqa: E402
+
+CANDS = [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24]      # the tuner's default candidate set (engine_base.h)
+
+# name, kind, rows, side, Cin, N  - M = rows * side^2; conv = 3x3 pad 1 (K = 9 * Cin)
+GEMMS = [
+    ("sd15 conv 64^2 320->320 (M=65536 N=320 K=2880)", "conv", 16, 64, 320, 320),
+    ("sd15 conv 64^2 640->320 (K=5760)", "conv", 16, 64, 640, 320),
+    ("sd15 conv 32^2 640->640 (M=16384 N=640 K=5760)", "conv", 16, 32, 640, 640),
+    ("sd15 conv 16^2 1280->1280 (M=4096 N=1280 K=11520)", "conv", 16, 16, 1280, 1280),
+    ("sd15 GEGLU 64^2 (M=65536 N=2560 K=320)", "geglu", 16, 64, 320, 2560),
+    ("sd15 GEGLU 32^2 (M=16384 N=5120 K=640)", "geglu", 16, 32, 640, 5120),
+    ("sd15 linear 64^2 320x320 +res (short K)", "lin", 16, 64, 320, 320),
+    ("sd15 QKV heads 64^2 (M=65536 N=960 K=320)", "lin", 16, 64, 320, 960),
+    ("sd15 FF-out 64^2 (M=65536 N=320 K=1280)", "lin", 16, 64, 1280, 320),
+    ("sdxl GEGLU 32^2 (M=4096 N=10240 K=1280)", "geglu", 4, 32, 1280, 10240),
+    ("sdxl FF-out 32^2 (M=4096 N=1280 K=5120)", "lin", 4, 32, 5120, 1280),
+    ("sdxl linear 32^2 1280x1280 +res (M=4096)", "lin", 4, 32, 1280, 1280),
+    ("sdxl QKV heads 32^2 (M=4096 N=3840 K=1280)", "lin", 4, 32, 1280, 3840),
+    ("sdxl conv 64^2 1920->640 (M=16384 N=640 K=17280)", "conv", 4, 64, 1920, 640),
+    ("sdxl conv 32^2 1280->1280 (M=4096 N=1280 K=11520)", "conv", 4, 32, 1280, 1280),
+    ("sdxl conv 128^2 320->320 (M=65536 N=320 K=2880)", "conv", 4, 128, 320, 320),
+    ("sdxl GEGLU 64^2 (M=16384 N=5120 K=640)", "geglu", 4, 64, 640, 5120),
+]
+# name, batch, heads, Nq, Nk, d
+ATTNS = [
+    ("sd15 self 64^2 (16x8 heads, N=4096, d=40)", 16, 8, 4096, 4096, 40),
+    ("sd15 self 32^2 (16x8 heads, N=1024, d=80)", 16, 8, 1024, 1024, 80),
+    ("sdxl self 32^2 (4x20 heads, N=1024, d=64)", 4, 20, 1024, 1024, 64),
+    ("sdxl self 64^2 (4x10 heads, N=4096, d=64)", 4, 10, 4096, 4096, 64),
+    ("sd15 cross 64^2 (16x8 heads, 4096 x 77, d=40)", 16, 8, 4096, 77, 40),
+    ("sdxl cross 32^2 (4x20 heads, 1024 x 77, d=64)", 4, 20, 1024, 77, 64),
+    ("sdxl cross 64^2 (4x10 heads, 4096 x 77, d=64)", 4, 10, 4096, 77, 64),
+]
+
+
+def timed(fn, iters):
+    """seconds per call: `iters` back-to-back calls between two events on the current stream, best of 3"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / iters * 1e-3)
+    return best
+
+
+def gemm_case(name, kind, R, side, Cin, N, iters):
+    M = R * side * side
+    g = torch.Generator(device="cuda").manual_seed(1)
+    if kind == "conv":
+        K = 9 * Cin
+        x = torch.zeros(R, side + 2, side + 2, Cin, device="cuda", dtype=torch.float16)
+        x[:, 1:-1, 1:-1] = torch.randn(R, side, side, Cin, device="cuda", dtype=torch.float16, generator=g)
+        w = torch.randn(N, K, device="cuda", dtype=torch.float16, generator=g) * K ** -0.5          # ours: [O][I/64][9][64]
+        o = H.empty_pn(R, side, side, N)
+        ours = lambda: H.igemm(x, None, Cin, 0, 9, 1, side, side, w, M, N, out=o, omode=1, old=N)  # noqa: E731
+        xv = x[:, 1:-1, 1:-1].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        wv = (torch.randn(N, Cin, 3, 3, device="cuda", dtype=torch.float16, generator=g) * K ** -0.5).contiguous(memory_format=torch.channels_last)
+        vendor = lambda: F.conv2d(xv, wv, None, 1, 1)  # noqa: E731
+        vname = "F.conv2d fp16 channels_last (MIOpen)"
+    else:
+        K = Cin
+        x = torch.randn(M, K, device="cuda", dtype=torch.float16, generator=g)
+        w = torch.randn(N, K, device="cuda", dtype=torch.float16, generator=g) * K ** -0.5
+        if kind == "geglu":
+            o = torch.empty(M, N // 2, device="cuda", dtype=torch.float16)
+            b = torch.zeros(N, device="cuda", dtype=torch.float32)
+            ours = lambda: H.igemm(x, None, K, 0, 1, 0, 0, 0, w, M, N, bias=b, out=o, omode=0, old=N // 2, epi=1)  # noqa: E731
+        else:
+            o = torch.empty(M, N, device="cuda", dtype=torch.float16)
+            ours = lambda: H.igemm(x, None, K, 0, 1, 0, 0, 0, w, M, N, out=o, omode=0, old=N)  # noqa: E731
+        vendor = lambda: F.linear(x, w)  # noqa: E731
+        vname = "F.linear fp16 (hipBLASLt)"
+    flops = 2.0 * M * N * K
+    lib = H.lib()
+    per_cfg = {}
+    lib.cfgpp_igemm_force_config(0)
+    t_heur = timed(ours, iters)
+    t_vendor = timed(vendor, iters)
+    for c in CANDS[1:]:
+        lib.cfgpp_igemm_force_config(c)
+        try:
+            per_cfg[c] = timed(ours, max(5, iters // 3))
+        except Exception:  # noqa: BLE001  (a tile that does not take this launch)
+            pass
+    lib.cfgpp_igemm_force_config(0)
+    best_c = min(per_cfg, key=per_cfg.get) if per_cfg else 0
+    if per_cfg:
+        lib.cfgpp_igemm_force_config(best_c)
+        t_best = min(timed(ours, iters), t_heur)
+        lib.cfgpp_igemm_force_config(0)
+    else:
+        t_best = t_heur
+    t_vendor = min(t_vendor, timed(vendor, iters))           # vendor again, after ours: alternation
+    return dict(name=name, kind=kind, M=M, N=N, K=K, ours_heuristic_TFs=flops / t_heur / 1e12, ours_best_tile_TFs=flops / t_best / 1e12,
+                ours_best_cfg=int(best_c if t_best < t_heur else 0), vendor_TFs=flops / t_vendor / 1e12, vendor=vname,
+                ours_us=t_best * 1e6, vendor_us=t_vendor * 1e6, vendor_over_ours=t_best / t_vendor)
+
+
+def attn_case(name, B, h, Nq, Nk, d, iters):
+    g = torch.Generator().manual_seed(2)
+    q, k, v = (torch.randn((B, h, n, d), generator=g).half().float() for n in (Nq, Nk, Nk))
+    hq, hk, hvt, qp, kp = H.make_heads(q, k, v)
+    ours = lambda: H.attention(hq, hk, hvt, B, h, d, Nq, Nk, qp, kp)  # noqa: E731
+    qd, kd, vd = (t.cuda().half() for t in (q, k, v))
+    vendor = lambda: F.scaled_dot_product_attention(qd, kd, vd)  # noqa: E731
+    flops = 4.0 * B * h * Nq * Nk * d
+    t_o = timed(ours, iters)
+    t_v = timed(vendor, iters)
+    t_o = min(t_o, timed(ours, iters))
+    t_v = min(t_v, timed(vendor, iters))
+    got = ours().float()
+    ref = vendor().transpose(1, 2).reshape(B, Nq, h * d).float()
+    rel = float((got - ref).norm() / ref.norm())
+    return dict(name=name, B=B, heads=h, Nq=Nq, Nk=Nk, d=d, ours_TFs=flops / t_o / 1e12, vendor_TFs=flops / t_v / 1e12,
+                vendor="F.scaled_dot_product_attention fp16", ours_us=t_o * 1e6, vendor_us=t_v * 1e6, vendor_over_ours=t_o / t_v,
+                rel_l2_ours_vs_vendor=rel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "yardstick.json"))
+    ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--filter", default="")
+    a = ap.parse_args()
+    from cfgpp_amd import _lib
+    torch.backends.cudnn.benchmark = True                    # MIOpen: let it search its solvers for these shapes
+    out = dict(device=torch.cuda.get_device_name(0), torch=torch.__version__, hip=torch.version.hip, build_id=_lib.build_id(),
+               iters=a.iters, when=time.strftime("%Y-%m-%d %H:%M:%S"), gemm=[], attention=[],
+               note="ours = libcfgpp_hip.so single-op hooks (fused epilogues included), vendor = torch-ROCm library kernels (plain GEMM / conv / SDPA); "
+                    "algorithmic TF/s, hot caches, best of 3 x iters back-to-back launches, one process, alternating")
+    for case in GEMMS:
+        if a.filter and a.filter not in case[0]:
+            continue
+        r = gemm_case(*case, iters=a.iters)
+        out["gemm"].append(r)
+        print(f"{r['name']:56s} ours {r['ours_heuristic_TFs']:6.0f} / best tile {r['ours_best_tile_TFs']:6.0f} (cfg {r['ours_best_cfg']:2d})   "
+              f"vendor {r['vendor_TFs']:6.0f} TF/s   vendor/ours {r['vendor_over_ours']:.2f}", flush=True)
+    for case in ATTNS:
+        if a.filter and a.filter not in case[0]:
+            continue
+        r = attn_case(*case, iters=a.iters)
+        out["attention"].append(r)
+        print(f"{r['name']:56s} ours {r['ours_TFs']:6.0f}   vendor {r['vendor_TFs']:6.0f} TF/s   vendor/ours {r['vendor_over_ours']:.2f}   "
+              f"rel-L2 {r['rel_l2_ours_vs_vendor']:.1e}", flush=True)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", a.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -49,3 +49,24 @@ def golden_r3():
     with open(os.path.join(ROOT, "tests", "golden", "sampler_golden_r3.json")) as f:
         meta = json.load(f)
     return g, meta
+
+
+# ---- order of the -m gpu suite: cheap -> expensive -------------------------------------------------------------------
+# The driver runs `pytest tests/ -x -q -m gpu`: with -x a failure (or a native abort) hides every test behind it, so the
+# single-kernel parity tests go first and the real-size nets (minutes each, tens of GB of host memory) go last.
+_GPU_FILE_ORDER = ["test_gpu_kernels.py", "test_gpu_step.py", "test_gpu_torch_semantics.py", "test_gpu_graph.py",
+                   "test_gpu_unet.py", "test_gpu_vae.py", "test_gpu_text.py", "test_gpu_weights.py", "test_gpu_examples.py",
+                   "test_gpu_configs.py", "test_gpu_realsize.py"]
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("CFGPP_TEST_ORDER") == "alpha":       # diagnostics: pytest's own order
+        return
+
+    def key(it_idx):
+        idx, it = it_idx
+        fname = os.path.basename(str(it.fspath))
+        if it.get_closest_marker("gpu") is None or fname not in _GPU_FILE_ORDER:
+            return (0, 0, idx)                                 # CPU tests and unknown files keep their place, first
+        return (1, _GPU_FILE_ORDER.index(fname), idx)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]

@@ -37,6 +37,20 @@ def test_library_exports_every_declared_symbol():
     assert _lib.last_error() == "" or isinstance(_lib.last_error(), str)
 
 
+def test_shipped_library_is_built_from_these_sources():
+    """provenance: the digest inside cfgpp_build_id() is the digest of the kernel sources + flags in THIS tree (build.py names its
+    object files by the same digests, so neither a stale object nor a stale library can pass for the current one)"""
+    from cfgpp_amd import _lib
+    from cfgpp_amd import build as B
+    B.build(verbose=False)
+    bid = _lib.build_id()
+    assert bid == B.library_build_id(), (bid, B.library_build_id())
+    tag, digest, head = bid.split(":")
+    assert tag == "cfgpp-build" and digest == B.source_digest() and head
+    objs = [f for f in os.listdir(B.OBJ) if f.endswith(".o")]
+    assert len(objs) == len(B.SOURCES), f"stale or missing objects: {sorted(objs)}"
+
+
 def test_shipped_kernels_have_no_spills_and_stay_in_their_register_budgets():
     """the gfx950 code objects inside the built library: no kernel spills VGPRs or uses scratch, and the kernels whose occupancy
     DESIGN.md counts on stay inside the register budget that occupancy needs (read from the ELF notes, scripts/kernel_resources.py)"""

@@ -5,11 +5,11 @@
   (UNet + fused step kernels + HIP VAE encode) against the SAME solver class on the CPU mock engine driving
   ``oracle/unet_ref.py`` - mirrors ``test_gpu_unet.py::test_sd_chain_vs_oracle`` for ``latent_sdxl.py:715-755,
   838-858,860-930,954-1025``;
-* one forward of the real SD1.5 net at the benchmark's own size (16 rows @ 64x64, autotuned tiles, K-split 8x8
-  level) and of the real SDXL net at 4 rows @ 128x128, and a 4-step real-SD1.5 batch-8 chain, vs the oracle;
+* (the real SD1.5 / SDXL nets at the benchmark's own sizes: tests/test_gpu_realsize.py);
+* attention and the VAE at the benchmark's own geometries;
 * the fp16-latent step kernel (inversion / edit dtype flow of the reference) bit-exact vs the golden vectors.
 
-Tolerances are 2x what was measured on the MI355X (recorded in gpurun_out/parity_r05.jsonl by these tests).
+Tolerances are 2x what was measured on the MI355X (recorded in gpurun_out/parity_<run>.jsonl by these tests).
 Both sides of a chain test use the same scalar semantics ("cuda" = the product default, see cfgpp_amd/coeffs.py).
 """
 import json
@@ -30,11 +30,15 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+_RUN_TAG = f"{time.strftime('%Y%m%d_%H%M%S')}_{os.getpid()}"
+
+
 def record(test, **kw):
-    """append measured errors to gpurun_out/parity_r05.jsonl (tolerances are set from these)"""
+    """measured errors of THIS run -> gpurun_out/parity_<start time>_<pid>.jsonl (one file per pytest process: numbers of
+    different builds never mix; tolerances are set from these)"""
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "parity_r05.jsonl"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", f"parity_{_RUN_TAG}.jsonl"), "a") as f:
             f.write(json.dumps(dict(test=test, **kw)) + "\n")
     except OSError:
         pass
@@ -272,132 +276,8 @@ def test_ancestral_solver_chain_vs_oracle_pinned_noise(name, lam, tol):
 
 
 # ------------------------------------------------------------------ the benchmark's own sizes
-@pytest.mark.parametrize("cfg_name,R,hw,tol", [("sd15", 16, 64, 2.5e-3)])
-def test_real_unet_forward_at_bench_size(cfg_name, R, hw, tol):
-    """C2's forward (SD1.5, 16 rows @ 64x64: autotuned 256-wide tiles, K-split 8x8 level, d = 40 attention at N = 4096)
-    vs the fp32 oracle; autotune ON."""
-    need_gpu()
-    import gpu_diag
-    t0 = time.time()
-    r = gpu_diag.unet_case(cfg_name, R, hw, tvals=(501.0,))
-    st = r["t501"]
-    record("real_unet_forward", cfg=cfg_name, rows=R, hw=hw, rel_l2=st["rel_l2"], max_abs=st["max_abs"], cpu_ref_s=st["cpu_ref_s"],
-           total_s=round(time.time() - t0, 1))
-    assert st["finite"] and st["rel_l2"] < tol, f"{cfg_name} rows={R} @{hw}: {st}"
-
-
-def test_real_sdxl_forward_at_every_bench_plan_size():
-    """The real SDXL net @ 128x128 latents at the row counts of all three SDXL workloads - 4 rows (C3: batch 2 per GPU),
-    2 rows (C5: batch-1 edit job; M = 2048 at the 32x32 level -> the K-split rule) and 16 rows (C4: Lightning batch 8;
-    16-row pools, multi-round grids) - vs the fp32 oracle, autotune ON.  The oracle runs ONCE on 4 distinct rows
-    (2 latents x {uc, c} contexts); the 2- and 16-row inputs are built from those rows (the net has no cross-row
-    term), so every output row of every plan has its own oracle row."""
-    need_gpu()
-    import hip_ops as H
-    from cfgpp_amd.engine import HipUNet
-    from cfgpp_amd.unet_config import CONFIGS
-    from cfgpp_amd.weights import synth_state_dict
-    from gpu_diag import rnd
-    from oracle.unet_ref import UNetRef
-    cfg, hw, tval = CONFIGS["sdxl"], 128, 501.0
-    sd = synth_state_dict(cfg, 0)
-    z = rnd(2, 4, hw, hw, seed=50)
-    ehs = rnd(4, 77, cfg.cross_attention_dim, scale=0.5, seed=51)
-    te = rnd(4, cfg.addition_pooled_dim, scale=0.5, seed=52)
-    ti = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * 4)
-    net = HipUNet(cfg, max_rows=16, sample_hw=(hw, hw))
-    net.load_state_dict(sd).finalize()
-    # oracle row j: latent j % 2, context j
-    plans = {4: ([0, 1], [0, 1, 2, 3]),
-             2: ([0], [0, 2]),
-             16: ([0, 1] * 4, [(r % 2) + 2 * ((r // 2) % 2) for r in range(16)])}
-    outs = {}
-    for R, (zi, ci) in plans.items():
-        net.set_context(ehs[ci], te[ci], ti[ci])
-        outs[R] = (net.forward(z[zi].to(H.DEV), tval).float().cpu(), ci)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    ref = UNetRef(cfg, sd)(torch.cat([z, z]), tval, ehs, {"text_embeds": te, "time_ids": ti})["sample"]
-    cpu_s = round(time.time() - t0, 1)
-    for R, (got, ci) in outs.items():
-        st = H.err_stats(got, ref[ci])
-        record("real_unet_forward", cfg="sdxl", rows=R, hw=hw, rel_l2=st["rel_l2"], max_abs=st["max_abs"], cpu_ref_s=cpu_s)
-        assert st["finite"] and st["rel_l2"] < 2.5e-3, f"sdxl rows={R} @{hw}: {st}"          # measured 1.1e-3 at 4 rows
-        worst = max(float((got[r] - ref[ci[r]]).norm() / ref[ci[r]].norm()) for r in range(R))
-        assert worst < 4e-3, f"sdxl rows={R}: worst single row rel-L2 {worst:.3e}"
-
-
-def test_real_sd15_batch8_chain_4_steps():
-    """4 NFE of the C2 job itself (real SD1.5 net, batch 8 -> UNet rows 16, 64x64 latents) vs UNetRef + oracle.sampler"""
-    need_gpu()
-    from cfgpp_amd.latent_diffusion import get_solver
-    from cfgpp_amd.schedule import SchedulerTables
-    from cfgpp_amd.unet_config import SD15 as cfg
-    from cfgpp_amd.weights import synth_state_dict
-    from oracle import sampler as O
-    from oracle.unet_ref import UNetRef
-    B, nfe, lam = 8, 4, 0.6
-    sc = types.SimpleNamespace(num_sampling=nfe)
-    hip = get_solver("ddim_cfg++", solver_config=sc, device="cuda", max_batch=B)
-    assert hip.scalar_semantics == "cuda"
-    prompts = [f"prompt {i}" for i in range(B)]
-    uc, c = hip.get_text_embed("bad", prompts)
-    seeds = list(range(100, 100 + B))
-    a = hip.sample(cfg_guidance=lam, prompt_embeds=(uc, c), seeds=seeds, return_latents=True)[0].float().cpu()
-    t0 = time.time()
-    net = UNetRef(cfg, synth_state_dict(cfg, 0))
-    ehs = torch.cat([uc.expand(B, -1, -1), c]).float().cpu()
-
-    def unet(z, t):
-        eps = net(torch.cat([z, z]), float(t), ehs)["sample"].half()
-        return eps[:B], eps[B:]
-    zT = hip._randn((B, 4, 64, 64), seeds=seeds)
-    ref, _ = O.sample_ddim(unet, zT, SchedulerTables(nfe), lam, cfgpp=True, semantics="cuda")
-    rel = rel_l2(a, ref)
-    record("real_sd15_b8_chain", nfe=nfe, rel_l2=rel, cpu_ref_s=round(time.time() - t0, 1))
-    assert torch.isfinite(a).all() and rel < 1e-3, f"chain rel-L2 {rel:.3e}"      # measured 4.1e-4
-
-
-def test_real_sdxl_chain_vs_oracle():
-    """The SDXL twin of test_real_sd15_batch8_chain_4_steps: the REAL SDXL net at 128 x 128 latents through get_solver(...) -
-    set_context with the added-condition embedding, UNet, fused step kernel, and for Lightning the lambda == 1 path that feeds
-    the UNet the positive rows only (Q7) - against the same solver class on the CPU mock engine driving UNetRef + the oracle's
-    arithmetic.  C3: 2 NFE of ddim_cfg++ at batch 2 (latent_sdxl.py:715-755); C4: 1 NFE of ddim_cfg++_lightning (838-858; batch 1
-    here - the CPU oracle costs ~35 s per UNet row).  One weight set and one oracle net serve both legs.
-    Tolerance = 2x the measured chain rel-L2 (4.2e-4 / 5.9e-4, gpurun_out/parity_r05.jsonl)."""
-    need_gpu()
-    from cfgpp_amd.latent_sdxl import get_solver
-    from cfgpp_amd.unet_config import SDXL as cfg
-    from cfgpp_amd.weights import synth_state_dict
-    from mock_engine import MockEngine
-    from oracle.unet_ref import UNetRef
-    hw = 128
-    sd = synth_state_dict(cfg, 0)
-    net = UNetRef(cfg, sd)
-
-    def unet(z, t, ehs, te, ti):
-        ack = {"text_embeds": te.float(), "time_ids": ti.float()}
-        return net(z.float(), t, ehs.float(), ack)["sample"].half()
-    for name, nfe, lam, B in (("ddim_cfg++", 2, 0.6, 2), ("ddim_cfg++_lightning", 1, 1.0, 1)):
-        sc = types.SimpleNamespace(num_sampling=nfe)
-        hip = get_solver(name, solver_config=sc, device="cuda", max_batch=B, scalar_semantics="cuda", unet_weights=sd)
-        assert (hip.engine.H, hip.engine.W) == (hw, hw)
-        prompts = ["a cat wearing a hat", "a dog on a skateboard"][:B]
-        pe = hip.get_text_embed("bad", prompts, "bad", prompts)
-        kw = dict(cfg_guidance=lam, target_size=(1024, 1024), original_size=(1024, 1024), seeds=[31, 32][:B], return_latents=True)
-        a = hip.sample(prompt_embeds=pe, **kw)
-        rows_seen = hip._ctx_keep[2].shape[0]
-        t0 = time.time()
-        ref = get_solver(name, solver_config=sc, device="cpu", max_batch=B, latent_hw=(hw, hw), text_encoder=hip.text_encoder,
-                         engine=MockEngine(unet, (hw, hw)), scalar_semantics="cuda")
-        b = ref.sample(prompt_embeds=tuple(x.cpu() for x in pe), **kw)
-        rel = rel_l2(a, b)
-        record("real_sdxl_chain", name=name, nfe=nfe, batch=B, rel_l2=rel, cpu_ref_s=round(time.time() - t0, 1))
-        assert a.shape == (B, 4, hw, hw) and torch.isfinite(a.float()).all() and rel < 1.5e-3, f"{name}: chain rel-L2 {rel:.3e}"
-        assert rows_seen == (B if lam == 1.0 else 2 * B)      # Q7: Lightning's conditioning block holds the positive rows only
-        del hip, ref
-        torch.cuda.empty_cache()
-
+# (the real SD1.5 / SDXL nets - forwards at every bench plan's row count and the real-net chains - live in
+#  tests/test_gpu_realsize.py: one subprocess per case, against fixtures recorded from the oracle in the build container)
 ATTN_CASES = [(1, 2, 4096, 4096, 40), (1, 2, 4096, 4096, 64), (2, 3, 1024, 1024, 64), (1, 2, 4096, 77, 40), (1, 2, 4096, 77, 64),
               (1, 2, 1024, 77, 64), (1, 2, 1024, 1024, 80), (1, 1, 256, 256, 160)]
 

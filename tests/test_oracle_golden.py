@@ -166,3 +166,24 @@ def test_whole_loop_driver_matches_golden(golden):
     z0t, zt = O.sample_ddim(unet, zT, tb, 0.6, cfgpp=True)
     assert torch.allclose(z0t, T(g[tag + "/z0t"])[-1], rtol=0, atol=2e-3)
     assert torch.allclose(zt, T(g[tag + "/zt"])[-1], rtol=0, atol=2e-3)
+
+
+def test_realsize_fixtures_are_present_and_shaped():
+    """the real-size oracle outputs recorded by tests/golden/make_unet_golden.py (used by the -m gpu real-size tests)"""
+    import json
+    import os
+
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    meta = json.load(open(os.path.join(here, "realsize_golden.json")))
+    want = {"sd15_fwd": {"eps": ([16, 4, 64, 64], "float16")}, "sdxl_fwd": {"eps": ([4, 4, 128, 128], "float16")},
+            "sd15_chain": {"z0t": ([8, 4, 64, 64], "float32")},
+            "sdxl_chain": {"ddim_cfg++": ([2, 4, 128, 128], "float32"), "ddim_cfg++_lightning": ([1, 4, 128, 128], "float32")}}
+    for case, arrays in want.items():
+        with np.load(os.path.join(here, f"realsize_{case}.npz")) as f:
+            assert set(f.files) == set(arrays), case
+            for k, (shape, dt) in arrays.items():
+                a = f[k]
+                assert list(a.shape) == shape and str(a.dtype) == dt and np.isfinite(a.astype(np.float32)).all(), (case, k)
+                assert 0.05 < float(np.abs(a.astype(np.float32)).mean()) < 10.0, (case, k)      # a real eps / latent, not zeros
+                assert meta[case]["arrays"][k] == [shape, dt]

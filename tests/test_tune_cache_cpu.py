@@ -88,3 +88,36 @@ def test_cache_switches(monkeypatch, tmp_path):
     off = PinCache("sd15", (64, 64), "x", "b", u.export, u.imp)
     u.forward(2)
     assert not off.save(2) and not off.load(2)
+
+
+def test_skewed_runs_do_not_persist_pins(tmp_path, monkeypatch):
+    """a profiled process (rocprofv3 exports ROCP_* into its child) or one with non-default tuner switches keeps its pins to itself"""
+    u = FakeUNet()
+    monkeypatch.setenv("ROCP_TOOL_LIB", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    c = _cache(u, tmp_path)
+    u.forward(16)
+    assert not c.save(16) and os.listdir(tmp_path) == []
+    monkeypatch.delenv("ROCP_TOOL_LIB")
+    state = [0xf1ffffff]
+    u2 = FakeUNet()
+    c2 = PinCache("sd15", (64, 64), "x", "b", u2.export, u2.imp, directory=str(tmp_path), knobs=lambda: (state[0],))
+    u2.forward(16)
+    state[0] = 0xffffffff                        # cfgpp_igemm_set_tune_mask(...) after the engine was built
+    assert not c2.save(16) and os.listdir(tmp_path) == []
+    state[0] = 0xf1ffffff
+    u2.forward(4)
+    assert c2.save(4) and len(os.listdir(tmp_path)) == 1
+
+
+def test_late_tuning_is_still_persisted_and_explicit_import_wins(tmp_path):
+    u = FakeUNet()
+    c = _cache(u, tmp_path)
+    assert not c.save(16)                        # first forward did not tune (e.g. stream capture): not definitive yet
+    u.forward(16)
+    assert c.save(16)                            # the second one did
+    # another rank: pins arrive by broadcast, the stale file on its disk must not replace them
+    u2 = FakeUNet()
+    c2 = _cache(u2, tmp_path)
+    u2.imp([1, 2, 3, 4, 5], 16)
+    c2.mark_imported(16)
+    assert not c2.load(16) and u2.imported[16] == [1, 2, 3, 4, 5] and not c2.save(16)
