@@ -185,5 +185,5 @@ def test_realsize_fixtures_are_present_and_shaped():
             for k, (shape, dt) in arrays.items():
                 a = f[k]
                 assert list(a.shape) == shape and str(a.dtype) == dt and np.isfinite(a.astype(np.float32)).all(), (case, k)
-                assert 0.05 < float(np.abs(a.astype(np.float32)).mean()) < 10.0, (case, k)      # a real eps / latent, not zeros
+                assert 0.05 < float(np.abs(a.astype(np.float32)).mean()) < 100.0, (case, k)     # a real eps / latent, not zeros (the 1-NFE Lightning z0t divides by sqrt(alpha_999) = 0.068)
                 assert meta[case]["arrays"][k] == [shape, dt]
