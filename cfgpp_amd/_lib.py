@@ -126,6 +126,7 @@ DEBUG_PROTOTYPES = {
     "cfgpp_attention_set_dma": (None, [_I]),
     "cfgpp_attention_set_stagger": (None, [_I]),
     "cfgpp_attention_set_cross": (None, [_I]),
+    "cfgpp_attention_set_waves": (None, [_I]),
 }
 
 _lib = None

@@ -28,6 +28,11 @@ SOURCES = [
     ("text.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# `python -m cfgpp_amd.build --asan`: a SECOND library, libcfgpp_hip_asan.so, whose HOST code is AddressSanitizer-instrumented
+# (device code is not: -fno-gpu-sanitize; GPU ASan / xnack+ objects are not available on the MI355X pool).  Development only:
+# load it with CFGPP_LIB=.../libcfgpp_hip_asan.so and LD_PRELOAD=$(clang -print-file-name=libclang_rt.asan-x86_64.so)
+# (scripts/r06_runs/asan_repro.sh).  The shipped library is never built this way.
+ASAN_FLAGS = ["-fsanitize=address", "-fno-gpu-sanitize", "-g", "-fno-omit-frame-pointer"]
 
 
 def _hipcc() -> str:
@@ -117,6 +122,38 @@ def library_build_id(path: str = OUT) -> str:
     return data[i:data.index(b"\0", i)].decode() if i >= 0 else ""
 
 
+def build_asan(verbose: bool = True) -> str:
+    """host-ASan twin of the library (see ASAN_FLAGS): own object directory, own output name"""
+    out = os.path.join(HERE, "libcfgpp_hip_asan.so")
+    obj_dir = os.path.join(CSRC, "_obj_asan")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    jobs, objs = [], []
+    for f, extra in SOURCES:
+        src = os.path.join(CSRC, f)
+        flags = COMMON + ASAN_FLAGS + extra
+        obj = os.path.join(obj_dir, f"{os.path.splitext(f)[0]}.{_digest(src, flags)}.o")
+        objs.append(obj)
+        if not os.path.exists(obj):
+            jobs.append((f, [hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj]))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for f, r in zip([j[0] for j in jobs], ex.map(lambda j: subprocess.run(j[1], capture_output=True, text=True), jobs)):
+            if verbose:
+                print(f"[cfgpp build asan] {f}: {'ok' if r.returncode == 0 else 'FAILED'}", flush=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {f}:\n{r.stdout}{r.stderr}")
+    bid_src = os.path.join(obj_dir, "build_id.cpp")
+    with open(bid_src, "w") as fh:
+        fh.write('extern "C" const char* cfgpp_build_id(void) { return "cfgpp-build:%s:%s+asan"; }\n' % (source_digest(), _git_head()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-o", out] + objs + [bid_src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("asan link failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(f"[cfgpp build asan] linked {out}", flush=True)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -169,5 +206,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(library_build_id())
+    if "--asan" in sys.argv:
+        print(build_asan())
+    else:
+        build(force="--force" in sys.argv)
+        print(library_build_id())

@@ -141,6 +141,28 @@ ORACLE = {"sd15_fwd": oracle_sd15_fwd, "sdxl_fwd": oracle_sdxl_fwd, "sd15_chain"
 
 
 # ---------------------------------------------------------------------------------------------------- HIP side (GPU box)
+def cached_weights(cfg, name):
+    """the seed-0 synthetic weights of `cfg` as (key, fp16 tensor) pairs.  Generating 2.6 G SDXL parameters takes a minute of one
+    CPU core; the values are fp16-exact by construction (weights.synth_tensor), so the first case that needs them leaves an fp16
+    copy under $TMPDIR and the other cases (own processes) read it back - lossless, and never part of the repo."""
+    import tempfile
+    from cfgpp_amd.weights import synth_state_dict_iter
+    path = os.path.join(os.environ.get("CFGPP_WEIGHT_CACHE", tempfile.gettempdir()), f"cfgpp_synth_{name}_seed0_fp16.pt")
+    if os.path.exists(path):
+        try:
+            return list(torch.load(path).items())
+        except Exception:  # noqa: BLE001  (a torn file of a killed run)
+            pass
+    items = [(k, v.half()) for k, v in synth_state_dict_iter(cfg, 0)]
+    try:
+        tmp = f"{path}.{os.getpid()}.tmp"
+        torch.save(dict(items), tmp)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+    return items
+
+
 def _build_id():
     from cfgpp_amd import _lib
     return _lib.build_id()
@@ -150,10 +172,9 @@ def hip_sd15_fwd():
     """autotune ON: 256-wide tiles, the K-split 8x8 level, d = 40 attention at N = 4096"""
     from cfgpp_amd.engine import HipUNet
     from cfgpp_amd.unet_config import SD15
-    from cfgpp_amd.weights import synth_state_dict_iter
     i, gold = sd15_fwd_inputs(), load_fixture("sd15_fwd")["eps"].float()
     net = HipUNet(SD15, max_rows=16, sample_hw=(64, 64))
-    net.load_state_dict(synth_state_dict_iter(SD15, 0)).finalize()
+    net.load_state_dict(cached_weights(SD15, "sd15")).finalize()
     net.set_context(i["ehs"])
     got = net.forward(i["z"].cuda(), TVAL).float().cpu()
     again = net.forward(i["z"].cuda(), TVAL).float().cpu()            # the tuned plan, second use
@@ -169,10 +190,9 @@ def hip_sdxl_fwd():
     rule at the 32 x 32 level) and 16 (C4, Lightning batch 8)"""
     from cfgpp_amd.engine import HipUNet
     from cfgpp_amd.unet_config import SDXL
-    from cfgpp_amd.weights import synth_state_dict_iter
     i, gold = sdxl_fwd_inputs(), load_fixture("sdxl_fwd")["eps"].float()
     net = HipUNet(SDXL, max_rows=16, sample_hw=(128, 128))
-    net.load_state_dict(synth_state_dict_iter(SDXL, 0)).finalize()
+    net.load_state_dict(cached_weights(SDXL, "sdxl")).finalize()
     res, ok = {}, True
     for R, (zi, ci) in SDXL_PLANS.items():
         net.set_context(i["ehs"][ci], i["te"][ci], i["ti"][ci])
@@ -187,8 +207,10 @@ def hip_sdxl_fwd():
 def hip_sd15_chain():
     """4 NFE of the C2 job itself: real SD1.5 net, batch 8 -> 16 UNet rows, through get_solver + the fused step kernel"""
     from cfgpp_amd.latent_diffusion import get_solver
+    from cfgpp_amd.unet_config import SD15
     c, gold = SD15_CHAIN, load_fixture("sd15_chain")["z0t"]
-    hip = get_solver(c["name"], solver_config=types.SimpleNamespace(num_sampling=c["nfe"]), device="cuda", max_batch=c["B"])
+    hip = get_solver(c["name"], solver_config=types.SimpleNamespace(num_sampling=c["nfe"]), device="cuda", max_batch=c["B"],
+                     unet_weights=iter(cached_weights(SD15, "sd15")))
     assert hip.scalar_semantics == "cuda"
     uc, cc = hip.get_text_embed("bad", c["prompts"])
     a = hip.sample(cfg_guidance=c["lam"], prompt_embeds=(uc, cc), seeds=c["seeds"], return_latents=True)[0].float().cpu()
@@ -198,12 +220,15 @@ def hip_sd15_chain():
 
 def hip_sdxl_chain():
     """C3: 2 NFE of ddim_cfg++ at batch 2; C4: 1 NFE of ddim_cfg++_lightning (lambda == 1: positive rows only, Q7)"""
+    from cfgpp_amd.hip_engine import HipEngine
     from cfgpp_amd.latent_sdxl import get_solver
+    from cfgpp_amd.unet_config import SDXL
     gold = load_fixture("sdxl_chain")
     res, ok = {}, True
+    eng = HipEngine(SDXL, max_batch=2, weights=iter(cached_weights(SDXL, "sdxl")))      # one engine serves both legs
     for leg in SDXL_CHAINS:
         hip = get_solver(leg["name"], solver_config=types.SimpleNamespace(num_sampling=leg["nfe"]), device="cuda", max_batch=leg["B"],
-                         scalar_semantics="cuda")
+                         scalar_semantics="cuda", engine=eng)
         p = SDXL_PROMPTS[:leg["B"]]
         pe = hip.get_text_embed("bad", p, "bad", p)
         a = hip.sample(prompt_embeds=pe, **_sdxl_kw(leg))
@@ -213,7 +238,6 @@ def hip_sdxl_chain():
         ok = (ok and tuple(a.shape) == (leg["B"], 4, 128, 128) and bool(torch.isfinite(a.float()).all()) and rel < 1.5e-3
               and rows_seen == (leg["B"] if leg["lam"] == 1.0 else 2 * leg["B"]))                    # measured 4.2e-4 / 5.9e-4
         del hip
-        torch.cuda.empty_cache()
     return dict(ok=ok, tol=1.5e-3, **res)
 
 
