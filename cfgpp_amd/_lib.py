@@ -126,7 +126,6 @@ DEBUG_PROTOTYPES = {
     "cfgpp_attention_set_dma": (None, [_I]),
     "cfgpp_attention_set_stagger": (None, [_I]),
     "cfgpp_attention_set_cross": (None, [_I]),
-    "cfgpp_attention_set_waves": (None, [_I]),
 }
 
 _lib = None

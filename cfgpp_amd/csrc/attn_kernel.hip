@@ -54,8 +54,7 @@ struct AttnArgs {
     int nq, nk_valid;     // real query / key counts
     int q_tok_pad, k_tok_pad;
     int o_ld;             // heads*d
-    int nqb;              // query blocks (of 128 queries; 64 for the two-wave workgroups) per batch*head; grid = nqb * B * heads workgroups
-    int nqb2;             // (host only) the 64-query block count
+    int nqb;              // query blocks (of 128 queries) per batch*head; grid = nqb * B * heads workgroups
     float scale_log2e;    // d^-0.5 * log2(e)
     int stagger;          // > 0: the co-resident workgroups of a CU start phase-shifted by this many 64-cycle sleeps (A/B knob)
 };
@@ -283,18 +282,13 @@ attn_kernel(const AttnArgs a) {
 // K tile  : LDS [64 keys  ][64 halfs], row = key,   16-B chunk c = 8 head dims
 // V^T tile: LDS [64 d-rows][64 keys ], row = d,     16-B chunk c = 8 (permuted) keys
 // physical chunk = logical chunk ^ ((row >> 1) & 7); one DMA piece = 8 rows x 128 B = 64 lanes x 16 B.
-// NW = waves per workgroup (32 queries each).  4 is the default; 2 (64-query workgroups, five of them = 160 KB of LDS per CU) is for
-// grids that leave the CUs unevenly loaded with 128-query blocks - SDXL's 32 x 32 level at 4 rows: 80 heads x 8 blocks = 640
-// workgroups on 256 CUs = 2.5 per CU, i.e. half the CUs run three and the launch lasts as long as those; 1280 two-wave
-// workgroups are exactly five per CU (the launcher picks, see cfgpp_op_attention).
-template <int D16, bool ONES, int NST, int WPE = 3, int NW = 4>        // NST = LDS ring stages (shipped: 2 = 32 KB); WPE = waves per SIMD the
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      // register allocation targets (4: <= 128 VGPRs, with NST = 2 four workgroups / CU)
+template <int D16, bool ONES, int NST, int WPE = 3>        // NST = LDS ring stages (shipped: 2 = 32 KB); WPE = waves per SIMD the
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))      // register allocation targets (4: <= 128 VGPRs, with NST = 2 four workgroups / CU)
 attn64_kernel(const AttnArgs a) {
     constexpr int DP = 64, DT = 2;
     constexpr int TILE = 64 * 128;               // bytes of one K or V^T tile
     constexpr int STAGE = 2 * TILE;
-    constexpr int RPW = 64 / NW;                 // tile rows (of K and of V^T) a wave brings in
-    constexpr int PPW = 2 * RPW / 8;             // DMA pieces per wave per tile: 8 (K) + 8 (V^T) over NW waves
+    constexpr int PPW = 4;                       // DMA pieces per wave per tile: 8 (K) + 8 (V^T) over 4 waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -302,20 +296,20 @@ attn64_kernel(const AttnArgs a) {
     const int l31 = lane & 31, hi = lane >> 5;
     int qb, bh;
     attn_block_map(a.nqb, qb, bh);
-    const int q0 = qb * (32 * NW) + wid * 32;
+    const int q0 = qb * 128 + wid * 32;
     const half_t* Qb = a.q + (long)bh * a.q_tok_pad * DP;
     const half_t* Kb = a.k + (long)bh * a.k_tok_pad * DP;
     const half_t* Vb = a.vt + (long)bh * DP * a.k_tok_pad;
 
     // DMA source addressing: lane -> (row r8 = lane >> 3 of the piece, physical chunk pc = lane & 7); the wave's
-    // pieces are K rows [RPW * wid, RPW * wid + RPW) and V^T rows [RPW * wid, RPW * wid + RPW) of the tile (RPW = 16 with four waves)
+    // pieces are K rows [16 * wid, 16 * wid + 16) and V^T rows [16 * wid, 16 * wid + 16) of the tile
     const int r8 = lane >> 3, pc = lane & 7;
     // (32-bit element offsets from the wave-uniform bases Kb / Vb: half the registers of per-lane 64-bit pointers, and the loads can
     // take the scalar-base + vector-offset form)
-    int koff[RPW / 8], voff[RPW / 8];
+    int koff[2], voff[2];
 #pragma unroll
-    for (int h = 0; h < RPW / 8; ++h) {
-        const int row = wid * RPW + h * 8 + r8;
+    for (int h = 0; h < 2; ++h) {
+        const int row = wid * 16 + h * 8 + r8;
         const int lc = pc ^ ((row >> 1) & 7);
         koff[h] = row * DP + lc * 8;                               // + t * 64 * DP per tile
         voff[h] = row * a.k_tok_pad + lc * 8;                      // + t * 64 per tile
@@ -326,11 +320,11 @@ attn64_kernel(const AttnArgs a) {
         const half_t* Kt = Kb + (long)t * 64 * DP;                 // (wave-uniform)
         const half_t* Vt = Vb + (long)t * 64;
 #pragma unroll
-        for (int h = 0; h < RPW / 8; ++h) {
+        for (int h = 0; h < 2; ++h) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kt + koff[h]),
-                                             (__attribute__((address_space(3))) void*)(Ks + (wid * RPW + h * 8) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(Ks + (wid * 16 + h * 8) * 128), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vt + voff[h]),
-                                             (__attribute__((address_space(3))) void*)(Vs + (wid * RPW + h * 8) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(Vs + (wid * 16 + h * 8) * 128), 16, 0, 0);
         }
     };
 
@@ -476,7 +470,7 @@ attn64_kernel(const AttnArgs a) {
         l_tot = l_run + __shfl_xor(l_run, 32);
     }
     const float inv_l = 1.0f / l_tot;
-    const int q = qb * (32 * NW) + wid * 32 + l31_f;
+    const int q = qb * 128 + wid * 32 + l31_f;
     if (q < a.nq) {
         const int b = bh / a.heads, head = bh - b * a.heads;
         half_t* orow = a.o + ((long)b * a.nq + q) * a.o_ld + head * a.d;
@@ -656,16 +650,16 @@ xattn64_kernel(const AttnArgs a, int xqb /* 128-query blocks per workgroup */, i
     }
 }
 
-template <int D16, bool ONES, int NST, int WPE = 3, int NW = 4>
+template <int D16, bool ONES, int NST, int WPE = 3>
 int launch_attn64(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int smem = NST * 2 * 64 * 128;
     static bool attr_set = false;
-    auto kern = attn64_kernel<D16, ONES, NST, WPE, NW>;
+    auto kern = attn64_kernel<D16, ONES, NST, WPE>;
     if (!attr_set) {
         CFGPP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
     return 0;
 }
 
@@ -699,7 +693,6 @@ static int g_attn_dma = 1;       // dp = 64: 1 = LDS-DMA kernel, 0 = register-st
                                  // tile t+1 and PV of tile t-1 issued between slices of tile t's softmax, two workgroups per CU - was +6..11 %
                                  // alone, neutral per forward and no better in matrix-pipe utilisation: commit 926a7ad)
 static int g_attn_cross = 1;     // dp = 64, <= 128 keys: 1 = the resident-K/V cross-attention kernel, 0 = the flash loop (A/B switch)
-static int g_attn_nw = 0;        // attn64_kernel workgroup size: 0 = by the grid rule in cfgpp_op_attention, 2 / 4 = forced
 static int g_attn_stagger = 0;   // attn64_kernel: phase shift between the workgroups of a CU, in 64-cycle sleeps per slot (0 = off)
 
 extern "C" {
@@ -707,7 +700,6 @@ extern "C" {
 void cfgpp_attention_set_dma(int mode) { g_attn_dma = mode ? 1 : 0; }
 void cfgpp_attention_set_stagger(int sleeps) { g_attn_stagger = sleeps > 0 ? sleeps : 0; }
 void cfgpp_attention_set_cross(int on) { g_attn_cross = on ? 1 : 0; }
-void cfgpp_attention_set_waves(int nw) { g_attn_nw = (nw == 2 || nw == 4) ? nw : 0; }
 
 // V^T contract: when d is not a multiple of 32, row d of every [dp][tok_pad] matrix must hold ones (softmax
 // denominator through the PV MFMA).  Call once after allocating / zeroing the buffer; the QKV epilogue never
@@ -736,7 +728,6 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
     a.o_ld = heads * d;
     a.scale_log2e = (1.0f / sqrtf((float)d)) * 1.4426950408889634f;
     a.nqb = cdiv(nq, 128);
-    a.nqb2 = cdiv(nq, 64);
     a.stagger = g_attn_stagger;
     dim3 grid(a.nqb * B * heads);
     hipStream_t s = (hipStream_t)stream;
@@ -766,19 +757,7 @@ int cfgpp_op_attention(const void* q, const void* k, const void* vt, void* o, in
         int rc;        // (a 2-stage ring was measured within 1 % of the 3-stage one and is not built)
         // four workgroups per CU: two-stage ring (32 KB), <= 128 VGPRs (the three-per-CU form on a 3-stage ring of rounds 2-3 measured
         // 3 - 9 % slower alone and 0.3 - 1 % per forward, profiles/r04/ab/attention_occupancy_call9.txt / _call10.txt)
-        // 64-query (two-wave) workgroups when the 128-query grid loads the CUs unevenly and the finer one does not.  For a grid of at
-        // most one round of resident workgroups (4 four-wave workgroups per CU; 5 two-wave ones fill its LDS: 5 x 32 KB) the launch lasts
-        // as long as the fullest CU: ceil(T / 256) workgroups of 128 queries, or ceil(2T / 256) of 64 queries = half the work each.
-        // SDXL 32 x 32 level at 4 rows: T = 640 -> 3 against 5 / 2.  g_attn_nw: 0 = this rule, 2 / 4 = forced (A/B).
-        const int T = (int)grid.x, T2 = a.nqb2 * B * heads;
-        const bool fine = g_attn_nw == 2 || (g_attn_nw == 0 && T <= 1024 && T2 <= 1280 && (T2 + 255) / 256 < 2 * ((T + 255) / 256));
-        if (fine) {
-            AttnArgs a2 = a; a2.nqb = a.nqb2;
-            const dim3 g2(T2);
-            // (five workgroups of two waves = at most three waves per SIMD: the register budget of three, no need to squeeze into 128)
-            if (d16 == 3) rc = launch_attn64<3, true, 2, 3, 2>(a2, g2, s);
-            else rc = ones ? launch_attn64<4, true, 2, 3, 2>(a2, g2, s) : launch_attn64<4, false, 2, 3, 2>(a2, g2, s);
-        } else if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
+        if (d16 == 3) rc = launch_attn64<3, true, 2, 4>(a, grid, s);
         else rc = ones ? launch_attn64<4, true, 2, 4>(a, grid, s) : launch_attn64<4, false, 2, 4>(a, grid, s);
         if (rc) return -1;
         CFGPP_HIP_CHECK(hipGetLastError());

@@ -56,8 +56,6 @@ void cfgpp_attention_set_stagger(int sleeps);
 /* A/B switch: 1 (default) attention with <= 128 keys and head dims padded to 64 (the 77-token cross-attention) runs the
  * resident-K/V single-pass kernel, 0 the flash loop */
 void cfgpp_attention_set_cross(int on);
-/* attn64_kernel workgroup size: 0 (default) = 64-query two-wave workgroups where the grid rule of cfgpp_op_attention says so, 2 / 4 = forced */
-void cfgpp_attention_set_waves(int nw);
 int cfgpp_op_conv_in(const void* z, int z_is_half, void* out, const float* w, const float* bias,
                      int R, int zB, int Cin, int H, int W, int Cout, void* stream);
 /* quant_conv (1x1, 8->8) + DiagonalGaussian posterior on the encoder's 8-channel conv_out (fp32 NCHW). */
