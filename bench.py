@@ -162,7 +162,7 @@ def cpu_baseline(cfg_name, name, nfe, lam, img, limit_s=240):
     return json.loads(lines[-1])
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def roofline_block(eng, config, B, dev, rnd):

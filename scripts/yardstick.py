@@ -53,6 +53,11 @@ GEMMS = [
     ("sdxl conv 32^2 1280->1280 (M=4096 N=1280 K=11520)", "conv", 4, 32, 1280, 1280),
     ("sdxl conv 128^2 320->320 (M=65536 N=320 K=2880)", "conv", 4, 128, 320, 320),
     ("sdxl GEGLU 64^2 (M=16384 N=5120 K=640)", "geglu", 4, 64, 640, 5120),
+    # the GEGLU shapes as PLAIN GEMMs on our side too (what the vendor column of the GEGLU rows computes): splits our GEGLU time
+    # into K loop + plain store and the fused gate epilogue
+    ("sd15 GEGLU-shape plain store 64^2 (M=65536 N=2560 K=320)", "lin", 16, 64, 320, 2560),
+    ("sd15 GEGLU-shape plain store 32^2 (M=16384 N=5120 K=640)", "lin", 16, 32, 640, 5120),
+    ("sdxl GEGLU-shape plain store 32^2 (M=4096 N=10240 K=1280)", "lin", 4, 32, 1280, 10240),
 ]
 # name, batch, heads, Nq, Nk, d
 ATTNS = [
@@ -115,10 +120,19 @@ def gemm_case(name, kind, R, side, Cin, N, iters):
     per_cfg = {}
     lib.cfgpp_igemm_force_config(0)
     t_heur = timed(ours, iters)
+    ref = o.clone()
     t_vendor = timed(vendor, iters)
     for c in CANDS[1:]:
+        # a FORCED config bypasses the launcher's validity rules (a GEGLU launch on a tile whose wave tiles split the (value | gate)
+        # column pairs computes garbage, fast): only configs whose output is bit-identical to the heuristic tile's count -
+        # which is also the library's own contract for every tile the tuner may pin
         lib.cfgpp_igemm_force_config(c)
         try:
+            o.zero_()
+            ours()
+            torch.cuda.synchronize()
+            if not torch.equal(o, ref):
+                continue
             per_cfg[c] = timed(ours, max(5, iters // 3))
         except Exception:  # noqa: BLE001  (a tile that does not take this launch)
             pass
