@@ -22,6 +22,7 @@ SOURCES = [
     ("small_kernels.hip", []),
     ("igemm_kernel.hip", []),
     ("big4_kernel.hip", []),
+    ("big4p_kernel.hip", []),
     ("attn_kernel.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # scores are consumed by VALU: keep MFMA results in VGPRs
     ("unet.hip", []),
     ("vae.hip", []),

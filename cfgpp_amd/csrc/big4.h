@@ -22,3 +22,11 @@ inline bool big4_supports(int cfg, const IGemmArgs& a, bool staged_epi) {
 }
 int big4_par_bytes(int BN, int nb);      // LDS bytes of the epilogue-parameter segments behind the ring (nb time-embedding rows)
 int big4_run(int cfg, const IGemmArgs& a, int grid, int smem, hipStream_t stream);
+
+// config 28 (big4p_kernel.hip): the 256 x 256 tile as a PERSISTENT kernel for token-major linears (amode 0, one source): one
+// workgroup per CU walks its share of the output tiles and prefetches the next tile's first K-tile under the epilogue.
+inline bool big4p_supports(const IGemmArgs& a, bool staged_epi) {
+    return a.amode == 0 && a.C1 == 0 && a.taps == 1 && a.temb == nullptr && big4_supports(24, a, staged_epi) && (long)a.K * 2 < (1L << 24);
+}
+int big4p_smem(int par_bytes_one);       // ring + two parameter-row buffers
+int big4p_run(const IGemmArgs& a, int grid, int smem, int par_bytes_one, hipStream_t stream);

@@ -81,7 +81,7 @@ struct EngineBase {
             tuned_rows = rows;
             return 0;
         }
-        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24, 25, 26, 27};
+        static const int cands[] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24, 25, 26, 27, 28};
         const size_t n = plan.size();
         plan_hint.resize(n, nullptr);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

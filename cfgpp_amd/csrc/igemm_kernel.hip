@@ -1470,6 +1470,22 @@ static int launch_big4(int cfg, const IGemmArgs& a_in, hipStream_t stream) {
     return big4_run(cfg, a, a.n_main, smem, stream);
 }
 
+static bool big4p_ok(const IGemmArgs& a) { return big4p_supports(a, g_staged_epi != 0) && big4p_smem(big4_par_bytes(256, 0)) <= 160 * 1024; }
+static int launch_big4p(const IGemmArgs& a_in, hipStream_t stream) {
+    IGemmArgs a = a_in;
+    a.par_nb = 0;                                      // (no time-embedding rows on a token-major linear: big4p_supports)
+    const int pb = big4_par_bytes(256, 0), smem = big4p_smem(pb);
+    const int ntm = cdiv(a.M, 256), ntn = cdiv(a.N, 256);
+    a.n_main = ntm * ntn; a.ksplit = 1; a.ws = nullptr; a.staged_epi = 1; a.tl = nullptr;
+    const double w_bytes = 2.0 * a.N * a.K, a_bytes = 2.0 * a.M * a.C0;
+    a.n_major = (g_n_major == 1 || (g_n_major < 0 && w_bytes > 1.5 * a_bytes && ntn >= 8)) ? 1 : 0;
+    if (g_n_major < 0 && a.walk_hint) a.n_major = a.walk_hint == 2 ? 1 : 0;
+    a.walk_div = a.n_major ? ntm : ntn;
+    walk_plan(a, 256, 256, ntm, ntn, smem);
+    stats_decide(a, true);
+    return big4p_run(a, a.n_main < 256 ? a.n_main : 256, smem, pb, stream);
+}
+
 static int g_force_cfg = 0;
 static int g_staging = 1;          // 1 = global_load_lds (default), 0 = register staging
 extern "C" void cfgpp_igemm_force_config(int cfg) { g_force_cfg = cfg; }
@@ -1527,6 +1543,9 @@ static int launch_config(int cfg, const IGemmArgs& a, hipStream_t stream) {
         case 19: return mf16_supports(a) ? launch_mf16<4>(a, stream) : launch_cfg<4, 1, 32, 160, true>(a, stream);
         // one wave per SIMD (big4_kernel.hip); launches they do not admit (generic epilogues, > 4 GiB operands) take the 128 x 128 tile
         case 24: case 25: case 26: return big4_ok(cfg, a) ? launch_big4(cfg, a, stream) : launch_cfg<2, 2, 64, 64, true>(a, stream);
+        // the 256 x 256 one-wave-per-SIMD tile as a persistent kernel with the next output tile's first K-tile prefetched under the
+        // epilogue (big4p_kernel.hip): token-major linears only
+        case 28: return big4p_ok(a) ? launch_big4p(a, stream) : launch_cfg<2, 2, 64, 64, true>(a, stream);
         default: cfgpp_set_error("igemm: bad config %d", cfg); return -2;
     }
 }
@@ -1662,7 +1681,7 @@ int igemm_launch(const IGemmArgs& a_in, hipStream_t stream) {
         const int h = a.cfg_hint & 63;
         const bool valid = (h == 1 || h == 4 || h == 6 || h == 12 || h == 14 || (h == 10 && a.epi == EPI_GEGLU) ||
                             ((h == 5 || h == 7 || h == 8 || h == 9 || h == 11) && a.epi != EPI_GEGLU) ||
-                            h == 13 || h == 15 || h == 16 || h == 17 || (h == 20 && a.epi != EPI_GEGLU) || (h == 27 && a.epi == EPI_STORE) || ((h >= 24 && h <= 26) && big4_ok(h, a))) && (g_big_tiles || h == 1);
+                            h == 13 || h == 15 || h == 16 || h == 17 || (h == 20 && a.epi != EPI_GEGLU) || (h == 27 && a.epi == EPI_STORE) || ((h >= 24 && h <= 26) && big4_ok(h, a)) || (h == 28 && big4p_ok(a))) && (g_big_tiles || h == 1);
         if (!rule_splits && valid) { cfg = h; a.allow_split = 0; g_last_hint_applied = 1; }
     }
     a.walk_hint = (g_force_cfg == 0 && g_staging != 0) ? (a.cfg_hint >> 6) & 3 : 0;      // tuner-pinned tile walk (0 = by operand bytes)

@@ -32,7 +32,7 @@ import torch.nn.functional as F  # noqa: E402
 
 import hip_ops as H  # noqa: E402
 
-CANDS = [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24]      # the tuner's default candidate set (engine_base.h)
+CANDS = [0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 20, 24, 28]      # the tuner's default candidate set (engine_base.h)
 
 # name, kind, rows, side, Cin, N  - M = rows * side^2; conv = 3x3 pad 1 (K = 9 * Cin)
 GEMMS = [

@@ -584,6 +584,60 @@ def t_big4():
     return out
 
 
+@case("big4p_persistent")
+def t_big4p():
+    """big4p_kernel (config 28: the 256 x 256 tile as a persistent kernel, 8 waves, the next output tile's first
+    K-tile prefetched under the epilogue) on token-major linears whose grids are several rounds of 256 workgroups, a tile count
+    that is not a multiple of 8 (the plain round-robin tile sequence), ragged edges, a single K-tile, every epilogue: right
+    against fp32, BIT-IDENTICAL to the 128 x 128 tile, identical run to run"""
+    out = {}
+    H.lib().cfgpp_igemm_set_tail_split(0)
+    shapes = (("store_res_640tiles", 16384, 2560, 320, True, 0), ("geglu_1280tiles", 16384, 5120, 640, False, 1),
+              ("store_299tiles", 5888, 3328, 128, False, 0), ("ragged_100tiles", 5000, 1032, 192, True, 0),
+              ("one_ktile", 8192, 1024, 64, False, 0), ("geglu_sdxl32", 4096, 10240, 1280, False, 1))
+    for name, M, N, K, resid, epi in shapes:
+        a = rnd(M, K, seed=len(name))
+        w = rnd(N, K, scale=K ** -0.5, seed=len(name) + 1)
+        b = rnd(N, scale=0.1, seed=len(name) + 2)
+        r = rnd(M, N, seed=len(name) + 3) if resid else None
+        ad, bd = a.to(H.DEV, torch.float16), b.to(H.DEV)
+        rd = r.to(H.DEV, torch.float16) if resid else None
+        if epi == 1:
+            h = a @ w.t() + b
+            v, g = h.chunk(2, dim=-1)
+            ref = v * F.gelu(g)
+            wd, bd = H.pack_geglu(w, b)
+        else:
+            ref = a @ w.t() + b + (r if resid else 0)
+            wd = w.to(H.DEV, torch.float16)
+        H.lib().cfgpp_igemm_force_config(1)
+        base = H.linear(ad, wd, bd, rd, epi=epi)
+        for c in (28,):
+            H.lib().cfgpp_igemm_force_config(c)
+            got = H.linear(ad, wd, bd, rd, epi=epi)
+            same = all(torch.equal(got, H.linear(ad, wd, bd, rd, epi=epi)) for _ in range(4))
+            out[f"{name}_cfg{c}"] = dict(H.err_stats(got, ref), identical_runs=bool(same), equals_cfg1=bool(torch.equal(got, base)))
+    for name, B, tokens, C, nheads in (("heads_d64_512tiles", 4, 4096, 640, 10), ("heads_d40", 4, 1024, 320, 8)):
+        a = rnd(B * tokens, C, seed=len(name) + 20)
+        w = rnd(3 * C, C, scale=C ** -0.5, seed=len(name) + 21)
+        ad, wd = a.to(H.DEV, torch.float16), w.to(H.DEV, torch.float16)
+        d = C // nheads
+        y = (a @ w.t()).reshape(B, tokens, 3, nheads, d)
+        H.lib().cfgpp_igemm_force_config(1)
+        base = H.heads_project(ad, wd, B, tokens, C, nheads, 0, 3, tokens, tokens)
+        for c in (28,):
+            H.lib().cfgpp_igemm_force_config(c)
+            hq, hk, hvt = H.heads_project(ad, wd, B, tokens, C, nheads, 0, 3, tokens, tokens)
+            eq = all(torch.equal(x, y_) for x, y_ in zip((hq, hk, hvt), base))
+            again = H.heads_project(ad, wd, B, tokens, C, nheads, 0, 3, tokens, tokens)
+            same = all(torch.equal(x, y_) for x, y_ in zip((hq, hk, hvt), again))
+            st = H.err_stats(hq[:, :tokens, :d].reshape(B, nheads, tokens, d), y[:, :, 0].permute(0, 2, 1, 3))
+            out[f"{name}_cfg{c}"] = dict(st, identical_runs=bool(same), equals_cfg1=bool(eq))
+    H.lib().cfgpp_igemm_force_config(0)
+    H.lib().cfgpp_igemm_set_tail_split(1)
+    return out
+
+
 @case("conv_in_out")
 def t_cio():
     out = {}

@@ -151,6 +151,14 @@ def test_one_wave_per_simd_tiles(diag):
     assert not bad, bad
 
 
+def test_persistent_256x256_tiles(diag):
+    """big4p_kernel (config 28): multi-round grids, odd tile counts, ragged edges, one K-tile, store / GEGLU / head-major
+    epilogues - parity vs fp32, bit-identical to the 128 x 128 igemm tile (the tuner may pin them), repeatable"""
+    r = _check(diag, diag.t_big4p, "big4p_persistent")
+    bad = {k: (v["identical_runs"], v["equals_cfg1"]) for k, v in r.items() if not (v["identical_runs"] and v["equals_cfg1"])}
+    assert not bad, bad
+
+
 def test_conv_in_out(diag):
     _check(diag, diag.t_cio, "conv_in_out")
 
