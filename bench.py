@@ -245,7 +245,7 @@ def roofline_block(eng, config, B, dev, rnd):
             pmc = json.load(open(pf))
         except Exception:  # noqa: BLE001
             pmc = None
-    out = {"bound": "mfma", "kernel": "implicit-GEMM family: igemm_kernel / igemm16_kernel / tile32_kernel (conv3x3, conv1x1, linear)", "achieved": round(ach, 1),
+    out = {"bound": "mfma", "kernel": "implicit-GEMM family: igemm_kernel / igemm16_kernel / tile32_kernel / big4_kernel / big4p_kernel (conv3x3, conv1x1, linear)", "achieved": round(ach, 1),
            "peak": PEAK_MFMA_FP16 / 1e12, "unit": "TFLOP/s", "frac": round(ach / (PEAK_MFMA_FP16 / 1e12), 4),
            "traffic": None if pmc is None else pmc["igemm"].get("hbm_bytes_per_launch"),
            "traffic_unit": "HBM bytes per igemm launch (rocprofv3 PMC passes over UNet-only forwards at this batch)",

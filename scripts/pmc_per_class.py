@@ -14,7 +14,7 @@ a = ap.parse_args()
 
 
 def is_igemm(k):
-    return ("igemm_kernel" in k or "igemm16_kernel" in k or "tile32_kernel" in k or "big4_kernel" in k) and "igemm_reduce" not in k
+    return ("igemm_kernel" in k or "igemm16_kernel" in k or "tile32_kernel" in k or "big4_kernel" in k or "big4p_kernel" in k) and "igemm_reduce" not in k
 
 
 def per_dispatch(d, counter):

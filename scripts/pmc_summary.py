@@ -7,7 +7,7 @@ import argparse, collections, csv, glob, json, os, re, sys
 
 def family(k):
     if "igemm_reduce" in k: return "igemm_reduce"
-    if "igemm_kernel" in k or "igemm16_kernel" in k or "tile32_kernel" in k or "big4_kernel" in k: return "igemm"   # every kernel of the implicit-GEMM family
+    if "igemm_kernel" in k or "igemm16_kernel" in k or "tile32_kernel" in k or "big4_kernel" in k or "big4p_kernel" in k: return "igemm"   # every kernel of the implicit-GEMM family
     if "attn64_kernel" in k or "xattn64_kernel" in k or "attn_kernel" in k: return "attention"
     if "gn_" in k: return "groupnorm"
     if "layernorm" in k: return "layernorm"

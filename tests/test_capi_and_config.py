@@ -81,6 +81,30 @@ def test_shipped_kernels_have_no_spills_and_stay_in_their_register_budgets():
     assert seen >= 8, "the occupancy-critical kernels were not found by name"
 
 
+def test_every_implicit_gemm_kernel_is_counted_in_the_pmc_family():
+    """scripts/pmc_summary.py folds rocprofv3 counters onto kernel families by NAME: every kernel of the shipped library that takes
+    an IGemmArgs block (the implicit-GEMM family - a new kernel file must not fall out of the roofline's traffic / mfma_util again,
+    as big4p_kernel did for one GPU call of round 6) has to map to "igemm" (or to the K-split reduce kernel)"""
+    import subprocess
+    import sys
+    from cfgpp_amd.build import build
+    build(verbose=False)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import kernel_resources as KR
+    src = open(os.path.join(ROOT, "scripts", "pmc_summary.py")).read()        # (a script: importing it would parse sys.argv)
+    ns = {}
+    exec(src[src.index("def family(k):"):src.index("def load(d):")], ns)
+    PS = type("PS", (), {"family": staticmethod(ns["family"])})
+    if not os.path.exists(KR.READELF):
+        pytest.skip("llvm-readelf not found")
+    ks = KR.kernels(os.path.join(ROOT, "cfgpp_amd", "libcfgpp_hip.so"))
+    names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in ks), capture_output=True, text=True).stdout.split("\n")
+    gemm = [n for n in names if "(IGemmArgs" in n]
+    assert len(gemm) > 40 and any("big4p_kernel" in n for n in gemm)
+    wrong = [n for n in gemm if PS.family(n) not in ("igemm", "igemm_reduce")]
+    assert wrong == [], wrong
+
+
 def test_param_totals_match_published_sizes():
     from cfgpp_amd.unet_config import SD15, SDXL, param_count
     assert param_count(SD15) == 859_520_964       # 859.5 M
