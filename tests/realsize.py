@@ -241,7 +241,27 @@ def hip_sdxl_chain():
     return dict(ok=ok, tol=1.5e-3, **res)
 
 
-HIP = {"sd15_fwd": hip_sd15_fwd, "sdxl_fwd": hip_sdxl_fwd, "sd15_chain": hip_sd15_chain, "sdxl_chain": hip_sdxl_chain}
+def hip_sd15_chain_graph():
+    """the same 4-NFE batch-8 job as hipGraph replays of one captured step (cfgpp_sample_graph_ddim) on the real net: against the
+    fixture, and bit-identical to the eager loop of the same solver"""
+    os.environ["CFGPP_GRAPH"] = "0"
+    from cfgpp_amd.latent_diffusion import get_solver
+    from cfgpp_amd.unet_config import SD15
+    c, gold = SD15_CHAIN, load_fixture("sd15_chain")["z0t"]
+    hip = get_solver(c["name"], solver_config=types.SimpleNamespace(num_sampling=c["nfe"]), device="cuda", max_batch=c["B"],
+                     unet_weights=iter(cached_weights(SD15, "sd15")))
+    uc, cc = hip.get_text_embed("bad", c["prompts"])
+    run = lambda: hip.sample(cfg_guidance=c["lam"], prompt_embeds=(uc, cc), seeds=c["seeds"], return_latents=True)[0].float().cpu()  # noqa: E731
+    eager = run()
+    os.environ["CFGPP_GRAPH"] = "1"
+    graph, again = run(), run()
+    rel = rel_l2(graph, gold)
+    same = bool(torch.equal(eager, graph)) and bool(torch.equal(graph, again))
+    return dict(ok=bool(torch.isfinite(graph).all()) and rel < 1e-3 and same, rel_l2=rel, graph_equals_eager=same, tol=1e-3)
+
+
+HIP = {"sd15_fwd": hip_sd15_fwd, "sdxl_fwd": hip_sdxl_fwd, "sd15_chain": hip_sd15_chain, "sdxl_chain": hip_sdxl_chain,
+       "sd15_chain_graph": hip_sd15_chain_graph}
 
 
 def main(argv):

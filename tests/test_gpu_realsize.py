@@ -52,6 +52,12 @@ def test_real_sd15_batch8_chain_4_steps_vs_oracle_fixture():
     run_case("sd15_chain")
 
 
+def test_real_sd15_chain_as_graph_replay_vs_oracle_fixture():
+    """the whole-loop hipGraph replay on the real SD1.5 net at batch 8: the fixture's tolerance, and bit-identical to the eager loop"""
+    res = run_case("sd15_chain_graph")
+    assert res["graph_equals_eager"]
+
+
 def test_real_sdxl_chains_vs_oracle_fixture():
     """C3 (2 NFE ddim_cfg++, batch 2) and C4 (1 NFE ddim_cfg++_lightning: positive rows only)"""
     res = run_case("sdxl_chain")
