@@ -64,6 +64,20 @@ def sdxl_fwd_inputs():
                 ti=torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * 4))
 
 
+def small_fwd_inputs(cfg, R, hw):
+    """the real nets at small row counts / other latent sizes (what tests/gpu_diag.py::unet_case feeds): SD1.5 2 rows @ 64 x 64,
+    SDXL 2 rows @ 32 x 32 latents; two timesteps (981 and 1: both ends of the sinusoid)"""
+    d = dict(z=rnd(R // 2, 4, hw, hw, seed=50), ehs=rnd(R, 77, cfg.cross_attention_dim, scale=0.5, seed=51), te=None, ti=None)
+    if cfg.addition_embed:
+        d["te"] = rnd(R, cfg.addition_pooled_dim, scale=0.5, seed=52)
+        d["ti"] = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * R)
+    return d
+
+
+SMALL_FWD = {"sd15_fwd_r2": ("sd15", 2, 64), "sdxl_fwd_r2_32": ("sdxl", 2, 32)}
+SMALL_TVALS = (981.0, 1.0)
+
+
 # oracle row j of the SDXL forward: latent j % 2, context j.  plan rows -> (latent index per z row, context index per UNet row)
 SDXL_PLANS = {4: ([0, 1], [0, 1, 2, 3]),
               2: ([0], [0, 2]),
@@ -98,6 +112,18 @@ def oracle_sdxl_fwd():
     eps = UNetRef(SDXL, synth_state_dict(SDXL, 0))(torch.cat([i["z"], i["z"]]), TVAL, i["ehs"],
                                                    {"text_embeds": i["te"], "time_ids": i["ti"]})["sample"]
     return dict(eps=eps.half().numpy())
+
+
+def _oracle_small_fwd(case):
+    from cfgpp_amd.unet_config import CONFIGS
+    from cfgpp_amd.weights import synth_state_dict
+    from oracle.unet_ref import UNetRef
+    name, R, hw = SMALL_FWD[case]
+    cfg = CONFIGS[name]
+    i = small_fwd_inputs(cfg, R, hw)
+    net = UNetRef(cfg, synth_state_dict(cfg, 0))
+    ack = {"text_embeds": i["te"], "time_ids": i["ti"]} if cfg.addition_embed else None
+    return {f"t{int(t)}": net(torch.cat([i["z"], i["z"]]), t, i["ehs"], ack)["sample"].half().numpy() for t in SMALL_TVALS}
 
 
 def oracle_sd15_chain():
@@ -137,7 +163,8 @@ def oracle_sdxl_chain():
     return out
 
 
-ORACLE = {"sd15_fwd": oracle_sd15_fwd, "sdxl_fwd": oracle_sdxl_fwd, "sd15_chain": oracle_sd15_chain, "sdxl_chain": oracle_sdxl_chain}
+ORACLE = {"sd15_fwd": oracle_sd15_fwd, "sdxl_fwd": oracle_sdxl_fwd, "sd15_chain": oracle_sd15_chain, "sdxl_chain": oracle_sdxl_chain,
+          "sd15_fwd_r2": lambda: _oracle_small_fwd("sd15_fwd_r2"), "sdxl_fwd_r2_32": lambda: _oracle_small_fwd("sdxl_fwd_r2_32")}
 
 
 # ---------------------------------------------------------------------------------------------------- HIP side (GPU box)
@@ -204,6 +231,24 @@ def hip_sdxl_fwd():
     return dict(ok=ok, tol=2.5e-3, **res)
 
 
+def _hip_small_fwd(case):
+    from cfgpp_amd.engine import HipUNet
+    from cfgpp_amd.unet_config import CONFIGS
+    name, R, hw = SMALL_FWD[case]
+    cfg = CONFIGS[name]
+    i, gold = small_fwd_inputs(cfg, R, hw), load_fixture(case)
+    net = HipUNet(cfg, max_rows=R, sample_hw=(hw, hw))
+    net.load_state_dict(cached_weights(cfg, name)).finalize()
+    net.set_context(i["ehs"], i["te"], i["ti"])
+    res, ok = {}, True
+    for t in SMALL_TVALS:
+        got = net.forward(i["z"].cuda(), t).float().cpu()
+        rel = rel_l2(got, gold[f"t{int(t)}"].float())
+        res[f"t{int(t)}"] = rel
+        ok = ok and bool(torch.isfinite(got).all()) and rel < 2.5e-3          # tests/test_gpu_unet.py: EPS_REL
+    return dict(ok=ok, tol=2.5e-3, **res)
+
+
 def hip_sd15_chain():
     """4 NFE of the C2 job itself: real SD1.5 net, batch 8 -> 16 UNet rows, through get_solver + the fused step kernel"""
     from cfgpp_amd.latent_diffusion import get_solver
@@ -261,7 +306,8 @@ def hip_sd15_chain_graph():
 
 
 HIP = {"sd15_fwd": hip_sd15_fwd, "sdxl_fwd": hip_sdxl_fwd, "sd15_chain": hip_sd15_chain, "sdxl_chain": hip_sdxl_chain,
-       "sd15_chain_graph": hip_sd15_chain_graph}
+       "sd15_chain_graph": hip_sd15_chain_graph,
+       "sd15_fwd_r2": lambda: _hip_small_fwd("sd15_fwd_r2"), "sdxl_fwd_r2_32": lambda: _hip_small_fwd("sdxl_fwd_r2_32")}
 
 
 def main(argv):

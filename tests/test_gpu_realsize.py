@@ -36,6 +36,14 @@ def run_case(case, timeout=600):
     return res
 
 
+@pytest.mark.parametrize("case", ["sd15_fwd_r2", "sdxl_fwd_r2_32"])
+def test_real_nets_at_small_row_counts_vs_oracle_fixture(case):
+    """SD1.5 2 rows @ 64 x 64 and SDXL 2 rows @ 32 x 32 latents at t = 981 and t = 1 (other plans, other K-split / tile rules than the
+    bench sizes)"""
+    res = run_case(case)
+    assert set(res) >= {"t981", "t1"}
+
+
 def test_real_sd15_forward_16_rows_vs_oracle_fixture():
     """C2's forward (16 rows @ 64 x 64, autotuned tiles, K-split 8 x 8 level, d = 40 attention over 4096 tokens)"""
     res = run_case("sd15_fwd")

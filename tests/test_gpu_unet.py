@@ -20,7 +20,9 @@ def diag():
     return gpu_diag
 
 
-@pytest.mark.parametrize("cfg_name,R,hw", [("tiny_sd", 4, 16), ("tiny_xl", 2, 16), ("tiny_sd", 6, 24), ("sd15", 2, 64), ("sdxl", 2, 32)])
+# (the real nets at these small row counts - SD1.5 2 rows @ 64 x 64, SDXL 2 rows @ 32 x 32 - moved to tests/test_gpu_realsize.py in
+#  round 6: same inputs, the oracle's output as a committed fixture instead of 30 - 120 s of CPU oracle on the GPU box)
+@pytest.mark.parametrize("cfg_name,R,hw", [("tiny_sd", 4, 16), ("tiny_xl", 2, 16), ("tiny_sd", 6, 24)])
 def test_unet_forward_vs_oracle(diag, cfg_name, R, hw):
     r = diag.unet_case(cfg_name, R, hw)
     from test_gpu_configs import record
@@ -126,7 +128,7 @@ def test_unet_output_does_not_depend_on_tile_tuning():
     outs = []
     try:
         lib.cfgpp_igemm_set_tail_split(0)
-        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14), (0, 24), (0, 25), (0, 26), (0, 27)):
+        for tune, force in ((0, 0), (1, 0), (0, 1), (0, 4), (0, 6), (0, 12), (0, 14), (0, 24), (0, 25), (0, 26), (0, 27), (0, 28)):
             lib.cfgpp_igemm_set_autotune(tune)
             lib.cfgpp_igemm_force_config(force)
             net = HipUNet(cfg, 8, (32, 32))

@@ -178,7 +178,9 @@ def test_realsize_fixtures_are_present_and_shaped():
     meta = json.load(open(os.path.join(here, "realsize_golden.json")))
     want = {"sd15_fwd": {"eps": ([16, 4, 64, 64], "float16")}, "sdxl_fwd": {"eps": ([4, 4, 128, 128], "float16")},
             "sd15_chain": {"z0t": ([8, 4, 64, 64], "float32")},
-            "sdxl_chain": {"ddim_cfg++": ([2, 4, 128, 128], "float32"), "ddim_cfg++_lightning": ([1, 4, 128, 128], "float32")}}
+            "sdxl_chain": {"ddim_cfg++": ([2, 4, 128, 128], "float32"), "ddim_cfg++_lightning": ([1, 4, 128, 128], "float32")},
+            "sd15_fwd_r2": {"t981": ([2, 4, 64, 64], "float16"), "t1": ([2, 4, 64, 64], "float16")},
+            "sdxl_fwd_r2_32": {"t981": ([2, 4, 32, 32], "float16"), "t1": ([2, 4, 32, 32], "float16")}}
     for case, arrays in want.items():
         with np.load(os.path.join(here, f"realsize_{case}.npz")) as f:
             assert set(f.files) == set(arrays), case
