@@ -147,3 +147,39 @@ def test_walk_plan_takes_the_blocked_walk_where_the_round_count_says_so():
     assert out[0] == 0, list(out)
     lib.cfgpp_igemm_walk_plan_probe(1000, 960, 320, 256, 320, 155136, 0, out)        # 4 x 3 = 12 tiles: not a multiple of 8
     assert out[0] == 0, list(out)
+
+
+def test_persistent_tile_sequence_covers_every_tile_exactly_once():
+    """big4p_kernel.hip: workgroup b of G = min(T, 256) walks tiles tile_index(0), tile_index(1), ... until -1.  Mirror of the
+    kernel's two forms - XCD x walks ITS contiguous eighth of the sequence G/8 tiles at a time (T % 8 == 0 and G % 8 == 0), else plain
+    rounds of G over the XCD-contiguous numbering - checked for: every tile exactly once, a workgroup's rounds are consecutive
+    (no gap before the -1), and in the XCD form every tile of XCD x lies in x's eighth (what keeps walk_plan's L2 model valid)."""
+    def seq(T, G, b):
+        xcd, idx = b & 7, b >> 3
+        by_xcd = T % 8 == 0 and G % 8 == 0
+        per, gx = T >> 3, G >> 3
+        out, r = [], 0
+        while True:
+            if by_xcd:
+                i = r * gx + idx
+                t = xcd * per + i if i < per else -1
+            else:
+                q, rr = G >> 3, G & 7
+                w0 = (xcd * (q + 1) if xcd < rr else rr * (q + 1) + (xcd - rr) * q) + idx
+                i = r * G + w0
+                t = i if i < T else -1
+            if t < 0:
+                return out
+            out.append(t)
+            r += 1
+    for T in (1, 7, 8, 27, 100, 240, 255, 256, 257, 299, 512, 640, 1280, 2560, 2563, 4096):
+        G = min(T, 256)
+        seen = []
+        for b in range(G):
+            s = seq(T, G, b)
+            assert s, (T, b)                       # every launched workgroup has at least one tile
+            seen += s
+            if T % 8 == 0 and G % 8 == 0:
+                per = T // 8
+                assert all((b & 7) * per <= t < ((b & 7) + 1) * per for t in s), (T, b)
+        assert sorted(seen) == list(range(T)), T
